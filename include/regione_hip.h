@@ -1,0 +1,154 @@
+/*
+ * regione_hip.h - C ABI of libregione_hip.so: RegionE's region-aware denoising hot path as
+ * hand-written HIP kernels for gfx950 (MI355X / CDNA4).
+ *
+ * The reference (Peyton-Chen/RegionE) is pure Python + one Triton kernel and has NO native
+ * surface; each entry point below names the reference Python function (file:line under
+ * /root/reference/RegionE/FluxKontext/) it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - tensors are dense row-major; `ld*` arguments are row strides in ELEMENTS;
+ *   - dtype codes: RGN_F32 = 0, RGN_BF16 = 1;
+ *   - `stream` is a hipStream_t (PyTorch: torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it, nothing synchronises, nothing allocates, buffers are borrowed;
+ *   - return value: 0 on success, otherwise a negative RGN_E_* code or a positive hipError_t;
+ *     rgn_last_error() returns a static string describing the last failure on this thread.
+ */
+#ifndef REGIONE_HIP_H
+#define REGIONE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGN_F32 0
+#define RGN_BF16 1
+
+#define RGN_E_BADARG (-1)
+#define RGN_E_UNSUPPORTED (-2)
+
+int rgn_version(void);
+const char* rgn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * a1/a2  Adaptive Region Partition.  Replaces token_selector (utils.py:282-354) + morphology
+ * (utils.py:124-237) + the one-step estimate of the scheduler (inplace.py:650).
+ *
+ *   est   = model_output ? f32(sample) + round_mo(round_mo(dt_final) * model_output) : f32(sample)
+ *   sim   = sum_d normalize(est)[d] * normalize(cond)[d]   (each normalised in its own dtype)
+ *   raw   = sim <= threshold
+ *   mask  = erosion_dilation ? dilate5x5(erode3x3cross(raw)) : raw     on the [h_tok,w_tok] grid
+ *   edited_ids / unedited_ids = ascending token ids with mask 1 / 0;  *count = number edited.
+ *
+ * sample [L,D] (f32 or bf16, upcast like inplace.py:610), model_output [L,D] or NULL,
+ * cond [L,D]; D must be 64 (packed 2x2x16 latent channels).  sim_out may be NULL.
+ * Two launches: rows -> similarity -> raw mask (one wave per token), then one workgroup does
+ * morphology in LDS and the ballot/popcount prefix-sum compaction.
+ */
+int rgn_arp_partition(const void* sample, int sample_dtype, const void* model_output, int mo_dtype,
+                      const void* cond, int cond_dtype, float dt_final, float threshold,
+                      int L, int D, int h_tok, int w_tok, int erosion_dilation,
+                      int64_t* edited_ids, int64_t* unedited_ids, uint8_t* raw_mask, uint8_t* mask,
+                      float* sim_out, int32_t* count, void* stream);
+
+/* a2 alone: remove_scattered_points (utils.py:214-237) on a u8 [h,w] mask + compaction. */
+int rgn_morph_compact(const uint8_t* raw_mask, int h_tok, int w_tok, int erosion_dilation,
+                      int64_t* edited_ids, int64_t* unedited_ids, uint8_t* mask, int32_t* count,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a3  ids_gather (utils.py:260-279) / ids_scatter (utils.py:240-257) on rows of `row_bytes`
+ * bytes (multiple of 4).  dst[k] = src[ids[k]]   /   dst[ids[k]] = src[k].   ids are int64.
+ */
+int rgn_gather_rows(const void* src, const int64_t* ids, void* dst, int K, int row_bytes, void* stream);
+int rgn_scatter_rows(const void* src, const int64_t* ids, void* dst, int K, int row_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a5  RegionEFlowMatchEulerDiscreteScheduler.step (inplace.py:581-691), arithmetic part.
+ *   out[l,:] = cast_v( f32(sample[l,:]) + round_v(round_v(dt_l) * v[l,:]) )
+ *   dt_l = mask ? (mask[l] ? dt : dt_direct) : dt        (split Euler on partition/refresh steps)
+ * sample f32|bf16, v f32|bf16, out has v's dtype (inplace.py:686).  Gather-free: one pass over
+ * the L rows instead of the reference's 4 gathers + 2 scatters + zeros + 2 axpy.
+ */
+int rgn_euler_step(const void* sample, int sample_dtype, const void* v, int v_dtype, void* out,
+                   const uint8_t* mask, float dt, float dt_direct, int L, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a6  Adaptive Velocity Decay cache hit (inplace.py:315-318):
+ *   out[k,:] = round_c( round_c(ratio) * cache[ids ? ids[k] : k, :] )
+ * The optional ids fuse the first-hit gather (inplace.py:316-317).
+ */
+int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio, void* out, int K, int D,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 MFMA GEMM  C = epilogue(A[M,K] @ W[N,K]^T + bias)  (fp32 accumulate).
+ * Replaces torch nn.Linear calls of the block bodies [EXT diffusers] and, with `out_rows`,
+ * the Triton index-scatter GEMM _partially_linear (fused_kernels.py:9-101).
+ *   epilogue: RGN_EPI_BIAS        C[r] = bf16(acc + bias)
+ *             RGN_EPI_GELU        C[r] = bf16(gelu_tanh(bf16(acc + bias)))  for columns >= gelu_from_col
+ *             RGN_EPI_GATE_RESID  C[r] = bf16(f32(resid[r]) + f32(bf16(gate[n] * bf16(acc + bias))))
+ *   r = out_rows ? out_rows[m] : m   (row scatter; out_rows int64 or NULL)
+ * K % 64 == 0; M, N arbitrary (>0).  resid uses ldc and may alias C.
+ */
+#define RGN_EPI_BIAS 0
+#define RGN_EPI_GELU 1
+#define RGN_EPI_GATE_RESID 2
+int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc,
+                  int M, int N, int K, int epilogue, int gelu_from_col, const void* gate,
+                  const void* resid, const int64_t* out_rows, void* stream);
+
+/* Skinny GEMV for the AdaLN modulation / timestep embedders:
+ *   y[b,n] = bf16( sum_k W[n,k] * act(x[b,k]) + bias[n] ),  act = silu (rounded to bf16) if silu_input.
+ * B <= 4, K % 8 == 0.  HBM-bound on W. */
+int rgn_gemv_bf16(const void* x, int ldx, const void* W, const void* bias, void* y, int ldy, int B, int N,
+                  int K, int silu_input, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm(eps, no affine) * (1 + scale) + shift over rows of width d (AdaLN-Zero modulate).
+ * Rows < split_row use (shift0, scale0), the others (shift1, scale1) - the text / image streams
+ * of a double block in one launch.  Rounding points follow the eager bf16 op sequence.
+ */
+int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int split_row,
+                    const void* shift0, const void* scale0, const void* shift1, const void* scale1,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Region-Instruction KV-cache write (RegoionEFluxAttnProcessor2_0, inplace.py:717-763,792-794):
+ * per-head RMSNorm(q), RMSNorm(k) + RoPE on raw projections and placement into the K / V^T slab.
+ *   qkv     [M, ld] bf16 with column blocks k_raw @ k_col, v_raw @ v_col, q_raw @ q_col (H*128 each)
+ *   q is normalised + rotated IN PLACE (cos/sin row = rope_q_rows ? rope_q_rows[m] : m of table q);
+ *   k row m goes to slab row kv_rows ? kv_rows[m] : m, rotated with the FULL-id table at that row
+ *     (MANAGER.image_rotary_emb, inplace.py:499);  v row m goes to column kvpos(row) of V^T.
+ *   rows < split_row use (wq0, wk0) RMSNorm weights (text stream: norm_added_q/k), others (wq1, wk1).
+ * K slab: [Skv_pad, H*128] bf16.  V^T slab: [H*128, Skv_pad] bf16 with the kv index permuted inside
+ * every 16-group (bits 2<->3 swapped) so that the attention kernel's PV operand is one 16-byte read.
+ */
+int rgn_qk_norm_rope_store(void* qkv, int ld, int k_col, int v_col, int q_col, int M, int H,
+                           int split_row, const void* wq0, const void* wk0, const void* wq1, const void* wk1,
+                           float eps, const float* cos_q, const float* sin_q, const float* cos_k,
+                           const float* sin_k, const int64_t* kv_rows, void* k_slab, void* vt_slab,
+                           int skv_pad, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Joint attention over the compacted query set against the full K/V cache; replaces
+ * flash_attn_func / SDPA (inplace.py:796-806).  softmax(Q K^T / sqrt(128)) V, non-causal,
+ * Sq != Skv allowed, head_dim 128, fp32 online softmax, bf16 MFMA.
+ *   Q [Sq, H*128] (row stride ldq) ; K slab / V^T slab as written by rgn_qk_norm_rope_store;
+ *   O [Sq, H*128] (row stride ldo), may alias Q (each workgroup reads its Q tile before writing).
+ */
+int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O,
+                  int ldo, int Sq, int Skv, int H, float scale, void* stream);
+
+/* Device properties the host side needs for roofline reporting (no torch types). */
+int rgn_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REGIONE_HIP_H */

@@ -1,0 +1,71 @@
+"""ctypes binding of libregione_hip.so (the C ABI declared in include/regione_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol cannot be
+resolved this module raises at import/first use - loudly - instead of degrading to eager torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+_c_void_p, _c_int, _c_float = C.c_void_p, C.c_int, C.c_float
+
+# name -> argtypes (restype is always int unless listed in _RESTYPE)
+SIGNATURES = {
+    "rgn_version": [],
+    "rgn_last_error": [],
+    "rgn_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)],
+    "rgn_arp_partition": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_float, _c_float,
+                          _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                          _c_void_p, _c_void_p, _c_void_p],
+    "rgn_morph_compact": [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "rgn_gather_rows": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "rgn_scatter_rows": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "rgn_euler_step": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_float, _c_float, _c_int,
+                       _c_int, _c_void_p],
+    "rgn_avd_apply": [_c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_int, _c_int, _c_void_p],
+    "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                      _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "rgn_gemv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                      _c_void_p],
+    "rgn_ln_modulate": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "rgn_qk_norm_rope_store": [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p,
+                               _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
+                               _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
+    "rgn_attention": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                      _c_float, _c_void_p],
+}
+_RESTYPE = {"rgn_last_error": C.c_char_p}
+
+_lib = None
+
+
+class RegionEHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise if the native library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RegionEHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback.")
+    h = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)           # AttributeError if the symbol is missing: loud by design
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    _lib = h
+    return h
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().rgn_last_error().decode(errors="replace")
+        raise RegionEHipError(f"{what or 'libregione_hip'} failed (rc={rc}): {msg}")

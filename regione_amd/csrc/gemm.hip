@@ -1,0 +1,290 @@
+// bf16 MFMA GEMM for gfx950:  C = epilogue(A[M,K] @ W[N,K]^T + bias), fp32 accumulate.
+//
+// Both operands are K-contiguous ("NT"), which is exactly what an MFMA 16x16x32 fragment wants:
+// every lane reads 8 consecutive k (16 B) of one row.  Structure (cdna_hip_programming.md section 5,
+// "step 3" + T1/T2):
+//   * 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles;
+//   * global -> LDS by `global_load_lds_dwordx4` (1 KiB per wave-instruction, no VGPR round trip),
+//     double buffered, one barrier per K-step;
+//   * LDS tile is [128 rows][64 k] bf16 (128 B rows).  The DMA destination is lane-linear, so the
+//     bank-conflict swizzle (16-B slot ^= row&7) is applied to the per-lane SOURCE address and to
+//     the ds_read_b128 address (rule 21: both sides or neither);
+//   * XCD-aware, bijective blockIdx -> tile map with GROUP_M ordering so that the tiles resident on
+//     one XCD share A / W panels in that XCD's private L2;
+//   * epilogue: accumulators + bias -> bf16 -> LDS C tile -> 16-byte row-contiguous stores with
+//     GELU-tanh / gated residual / row scatter fused in.
+//
+// Replaces: nn.Linear calls of the [EXT] MMDiT blocks and, with out_rows, the Triton index-scatter
+// GEMM `_partially_linear` (RegionE/FluxKontext/fused_kernels.py:9-101).  Unlike the Triton kernel
+// the result is rounded ONCE to the cache dtype (no fp16 round trip, quirk A-3).
+#include "common.h"
+
+namespace rgn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct GemmArgs {
+    const uint16_t* A;
+    const uint16_t* W;
+    const uint16_t* bias;
+    uint16_t* C;
+    const uint16_t* gate;
+    const uint16_t* resid;
+    const int64_t* out_rows;
+    int lda, ldw, ldc;
+    int M, N, K;
+    int gelu_from_col;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
+constexpr int CT_LD = BN + 8;                    // padded bf16 row of the C staging tile
+
+__device__ __forceinline__ float gelu_tanh(float x) {
+    // torch GELU(approximate='tanh') opmath: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
+    const float kBeta = 0.7978845608028654f * 1.0f, kKappa = 0.044715f;
+    float inner = kBeta * (x + kKappa * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware bijective tile map (T1) + grouped ordering --------------------------------
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN, nt = ntm * ntn;
+    int t;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+        const int q = nt >> 3, r = nt & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * ntn;
+    const int group = t / per_group, first_m = group * GROUP_M;
+    const int gsize = min(ntm - first_m, GROUP_M);
+    const int tm = first_m + (t % per_group) % gsize;
+    const int tn = (t % per_group) / gsize;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- staging addresses: 4 A + 4 B DMA pieces per wave per stage --------------------------
+    const int srow = lane >> 3;                    // row inside an 8-row piece
+    const int schunk = (lane & 7) ^ srow;          // source 16-B chunk for LDS slot (lane&7)
+    const uint8_t* a_src[4];
+    const uint8_t* b_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 8 + srow;
+        const int ar = min(m0 + row, g.M - 1), br = min(n0 + row, g.N - 1);
+        a_src[q] = (const uint8_t*)(g.A + (size_t)ar * g.lda) + schunk * 16;
+        b_src[q] = (const uint8_t*)(g.W + (size_t)br * g.ldw) + schunk * 16;
+    }
+    auto stage = [&](int kt, int buf) {
+        uint8_t* base = smem + buf * STAGE_BYTES + (wave * 4) * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[q] + (size_t)kt * (BK * 2)),
+                                             (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(b_src[q] + (size_t)kt * (BK * 2)),
+                                             (lds_ptr_t)(base + TILE_BYTES + q * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (swizzled) -----------------------------------------------------
+    const int frow = lane & 15, fk = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int slot = (kk * 4 + fk) ^ (frow & 7);
+        a_off[kk] = (wm * 64 + frow) * 128 + slot * 16;
+        b_off[kk] = TILE_BYTES + (wn * 64 + frow) * 128 + slot * 16;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const uint8_t* sb = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf8_t*)(sb + a_off[kk] + i * 2048);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc + bias -> bf16 -> LDS C tile -------------------------------------------
+    uint16_t* ct = (uint16_t*)smem;                 // 128 x CT_LD bf16 = 34 KiB (stages are free now)
+    {
+        const int ccol = lane & 15, crow = (lane >> 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + ccol;
+            const float bv = (g.bias != nullptr && n < g.N) ? bf2f(g.bias[n]) : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ct[(wm * 64 + i * 16 + crow + r) * CT_LD + wn * 64 + j * 16 + ccol] = f2bf(acc[i][j][r] + bv);
+        }
+    }
+    __syncthreads();
+    // ---- 16-byte row-contiguous stores with the fused epilogue --------------------------------
+    const int vc = tid & 15;                         // 8-column vector inside the tile row
+    const int ncol = n0 + vc * 8;
+    const bool full_vec = (ncol + 8 <= g.N);
+    uint16_t gv[8];
+    if (EPI == RGN_EPI_GATE_RESID) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = (ncol + e < g.N) ? g.gate[ncol + e] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = (tid >> 4) + it * 16;
+        const int m = m0 + row;
+        if (m >= g.M || ncol >= g.N) continue;
+        const size_t orow = g.out_rows ? (size_t)g.out_rows[m] : (size_t)m;
+        uint16_t v[8];
+        *(uint4*)v = *(const uint4*)(ct + row * CT_LD + vc * 8);
+        uint16_t* dst = g.C + orow * g.ldc + ncol;
+        if (EPI == RGN_EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));
+        } else if (EPI == RGN_EPI_GATE_RESID) {
+            const uint16_t* rs = g.resid + orow * g.ldc + ncol;
+            uint16_t rv[8];
+            if (full_vec) *(uint4*)rv = *(const uint4*)rs;
+            else
+                for (int e = 0; e < 8; ++e) rv[e] = (ncol + e < g.N) ? rs[e] : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float gated = rbf(bf2f(gv[e]) * bf2f(v[e]));      // gate.unsqueeze(1) * out (bf16)
+                v[e] = f2bf(bf2f(rv[e]) + gated);                         // residual + ... (bf16)
+            }
+        }
+        if (full_vec) *(uint4*)dst = *(const uint4*)v;
+        else
+            for (int e = 0; e < 8; ++e)
+                if (ncol + e < g.N) dst[e] = v[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMV: one wave per output row n, lanes stride K in 16-byte vectors.  HBM-bound on W.
+// ------------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const uint16_t* __restrict__ x, int ldx,
+                                                        const uint16_t* __restrict__ W,
+                                                        const uint16_t* __restrict__ bias,
+                                                        uint16_t* __restrict__ y, int ldy, int N, int K,
+                                                        int silu_input) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[B];
+#pragma unroll
+    for (int b = 0; b < B; ++b) acc[b] = 0.f;
+    const uint16_t* wr = W + (size_t)n * K;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        uint16_t wv[8];
+        *(uint4*)wv = *(const uint4*)(wr + k);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            uint16_t xv[8];
+            *(uint4*)xv = *(const uint4*)(x + (size_t)b * ldx + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float xf = bf2f(xv[e]);
+                if (silu_input) xf = rbf(xf / (1.0f + expf(-xf)));     // F.silu in bf16: fp32 math, bf16 out
+                acc[b] += xf * bf2f(wv[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        float s = wave_sum(acc[b]);
+        if (lane == 0) y[(size_t)b * ldy + n] = f2bf(s + (bias ? bf2f(bias[n]) : 0.f));
+    }
+}
+
+}  // namespace rgn
+
+using namespace rgn;
+
+extern "C" {
+
+int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
+                  int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
+                  const int64_t* out_rows, void* stream) {
+    if (M == 0) return 0;
+    if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return fail(RGN_E_BADARG, "gemm: bad argument");
+    if (K % BK != 0) return fail(RGN_E_UNSUPPORTED, "gemm: K must be a multiple of 64");
+    if ((lda % 8) || (ldw % 8) || (ldc % 8)) return fail(RGN_E_UNSUPPORTED, "gemm: row strides must be multiples of 8");
+    if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)resid) & 15) != 0)
+        return fail(RGN_E_UNSUPPORTED, "gemm: pointers must be 16-byte aligned");
+    if (epilogue == RGN_EPI_GATE_RESID && (!gate || !resid)) return fail(RGN_E_BADARG, "gemm: gate/resid missing");
+    GemmArgs g;
+    g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.bias = (const uint16_t*)bias; g.C = (uint16_t*)C;
+    g.gate = (const uint16_t*)gate; g.resid = (const uint16_t*)resid; g.out_rows = out_rows;
+    g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.gelu_from_col = gelu_from_col;
+    const int nt = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const size_t lds = 2 * STAGE_BYTES;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    switch (epilogue) {
+        case RGN_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<RGN_EPI_BIAS>, dim3(nt), dim3(256), lds, st, g); break;
+        case RGN_EPI_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<RGN_EPI_GELU>, dim3(nt), dim3(256), lds, st, g); break;
+        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<RGN_EPI_GATE_RESID>, dim3(nt), dim3(256), lds, st, g); break;
+        default: return fail(RGN_E_BADARG, "gemm: unknown epilogue");
+    }
+    return check_launch("gemm_bf16_kernel");
+}
+
+int rgn_gemv_bf16(const void* x, int ldx, const void* W, const void* bias, void* y, int ldy, int B, int N, int K,
+                  int silu_input, void* stream) {
+    if (!x || !W || !y || B < 1 || B > 4 || N <= 0 || K <= 0 || (K % 8) || (ldx % 8))
+        return fail(RGN_E_BADARG, "gemv: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((N + 3) / 4), blk(256);
+    const uint16_t *xx = (const uint16_t*)x, *ww = (const uint16_t*)W, *bb = (const uint16_t*)bias;
+    uint16_t* yy = (uint16_t*)y;
+    switch (B) {
+        case 1: hipLaunchKernelGGL(gemv_bf16_kernel<1>, grid, blk, 0, st, xx, ldx, ww, bb, yy, ldy, N, K, silu_input); break;
+        case 2: hipLaunchKernelGGL(gemv_bf16_kernel<2>, grid, blk, 0, st, xx, ldx, ww, bb, yy, ldy, N, K, silu_input); break;
+        case 3: hipLaunchKernelGGL(gemv_bf16_kernel<3>, grid, blk, 0, st, xx, ldx, ww, bb, yy, ldy, N, K, silu_input); break;
+        default: hipLaunchKernelGGL(gemv_bf16_kernel<4>, grid, blk, 0, st, xx, ldx, ww, bb, yy, ldy, N, K, silu_input); break;
+    }
+    return check_launch("gemv_bf16_kernel");
+}
+
+}  // extern "C"

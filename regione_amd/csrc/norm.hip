@@ -1,0 +1,200 @@
+// Row-wise kernels of the masked MMDiT block: AdaLN modulate, per-head RMSNorm + RoPE on Q/K with
+// placement of K / V^T into the Region-Instruction KV-cache slab.  All HBM-streaming; rounding
+// points follow the eager bf16 op sequence of the [EXT] diffusers modules the reference calls
+// (inplace.py:518-555 blocks, :760-763 norm_q/norm_k, :792-794 apply_rotary_emb).
+#include "common.h"
+
+namespace rgn {
+
+// ------------------------------------------------------------------------------------------------
+// y = bf16(bf16(bf16(LN(x)) * bf16(1 + scale)) + shift), one 256-thread block per row, two-pass stats
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const uint16_t* __restrict__ x, int ldx,
+                                                          uint16_t* __restrict__ out, int ldo, int d, float eps,
+                                                          int split_row, const uint16_t* __restrict__ shift0,
+                                                          const uint16_t* __restrict__ scale0,
+                                                          const uint16_t* __restrict__ shift1,
+                                                          const uint16_t* __restrict__ scale1) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t* xr = x + (size_t)row * ldx;
+    const uint16_t* sh = row < split_row ? shift0 : shift1;
+    const uint16_t* sc = row < split_row ? scale0 : scale1;
+    const int nvec = d >> 3;
+    constexpr int MAXV = 4;                       // d <= 8192
+    float v[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = tid + i * 256;
+        if (vi < nvec) {
+            uint16_t t[8];
+            *(uint4*)t = *(const uint4*)(xr + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = tid + i * 256;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; q += c * c; }
+        }
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    uint16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = tid + i * 256;
+        if (vi < nvec) {
+            uint16_t a[8], b[8], o[8];
+            *(uint4*)a = *(const uint4*)(sc + vi * 8);
+            *(uint4*)b = *(const uint4*)(sh + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float y0 = rbf((v[i][e] - mean) * rstd);          // LayerNorm output (bf16)
+                const float s1 = rbf(1.0f + bf2f(a[e]));                // (1 + scale) (bf16)
+                const float y1 = rbf(y0 * s1);
+                o[e] = f2bf(y1 + bf2f(b[e]));
+            }
+            *(uint4*)(orow + vi * 8) = *(const uint4*)o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Q/K: per-head RMSNorm + RoPE.  One wave per token row, lane = one rotary pair (2 of 128 dims),
+// loop over heads so the cos/sin pairs are loaded once per row.
+//   q: in place.   k: -> K slab row (kv_rows ? kv_rows[m] : m), rotated with the FULL-id table.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict__ qkv, int ld, int k_col, int q_col,
+                                                           int M, int H, int split_row,
+                                                           const uint16_t* __restrict__ wq0, const uint16_t* __restrict__ wk0,
+                                                           const uint16_t* __restrict__ wq1, const uint16_t* __restrict__ wk1,
+                                                           float eps, const float* __restrict__ cos_q,
+                                                           const float* __restrict__ sin_q, const float* __restrict__ cos_k,
+                                                           const float* __restrict__ sin_k,
+                                                           const int64_t* __restrict__ kv_rows,
+                                                           uint16_t* __restrict__ k_slab) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const size_t kr = kv_rows ? (size_t)kv_rows[m] : (size_t)m;
+    const uint16_t* wq = m < split_row ? wq0 : wq1;
+    const uint16_t* wk = m < split_row ? wk0 : wk1;
+    const float2 cq = *(const float2*)(cos_q + (size_t)m * 128 + lane * 2);
+    const float2 sq = *(const float2*)(sin_q + (size_t)m * 128 + lane * 2);
+    const float2 ck = *(const float2*)(cos_k + kr * 128 + lane * 2);
+    const float2 sk = *(const float2*)(sin_k + kr * 128 + lane * 2);
+    const uint32_t wqp = *(const uint32_t*)(wq + lane * 2), wkp = *(const uint32_t*)(wk + lane * 2);
+    const float wq_a = bf2f(wqp & 0xffff), wq_b = bf2f(wqp >> 16), wk_a = bf2f(wkp & 0xffff), wk_b = bf2f(wkp >> 16);
+    uint16_t* row = qkv + (size_t)m * ld;
+    const size_t HD = (size_t)H * 128;
+#pragma unroll 4
+    for (int h = 0; h < H; ++h) {
+        uint32_t* qp = (uint32_t*)(row + q_col + h * 128 + lane * 2);
+        const uint32_t qv = *qp;
+        const uint32_t kv = *(const uint32_t*)(row + k_col + h * 128 + lane * 2);
+        float qa = bf2f(qv & 0xffff), qb = bf2f(qv >> 16), ka = bf2f(kv & 0xffff), kb = bf2f(kv >> 16);
+        // RMSNorm: fp32 variance, x*rsqrt in fp32, round to bf16, times bf16 weight (round)
+        const float rq = 1.0f / sqrtf(wave_sum(qa * qa + qb * qb) * (1.0f / 128.0f) + eps);
+        const float rk = 1.0f / sqrtf(wave_sum(ka * ka + kb * kb) * (1.0f / 128.0f) + eps);
+        qa = rbf(rbf(qa * rq) * wq_a); qb = rbf(rbf(qb * rq) * wq_b);
+        ka = rbf(rbf(ka * rk) * wk_a); kb = rbf(rbf(kb * rk) * wk_b);
+        // RoPE (fp32): out[2i] = x[2i]*cos - x[2i+1]*sin ; out[2i+1] = x[2i+1]*cos + x[2i]*sin
+        const float q0 = __fadd_rn(__fmul_rn(qa, cq.x), __fmul_rn(-qb, sq.x));
+        const float q1 = __fadd_rn(__fmul_rn(qb, cq.y), __fmul_rn(qa, sq.y));
+        const float k0 = __fadd_rn(__fmul_rn(ka, ck.x), __fmul_rn(-kb, sk.x));
+        const float k1 = __fadd_rn(__fmul_rn(kb, ck.y), __fmul_rn(ka, sk.y));
+        *qp = (uint32_t)f2bf(q0) | ((uint32_t)f2bf(q1) << 16);
+        *(uint32_t*)(k_slab + kr * HD + h * 128 + lane * 2) = (uint32_t)f2bf(k0) | ((uint32_t)f2bf(k1) << 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V: transpose 64 rows x 128 dims (one head) through LDS into the V^T slab, kv index permuted inside
+// every 16-group (bits 2<->3 swapped): that is the order in which the attention kernel's S^T
+// accumulator registers line up as the P operand, so its V^T operand is one 16-byte LDS read.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t kvpos(size_t r) { return (r & ~(size_t)12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+__global__ __launch_bounds__(256) void v_transpose_store_kernel(const uint16_t* __restrict__ qkv, int ld, int v_col,
+                                                                int M, const int64_t* __restrict__ kv_rows,
+                                                                uint16_t* __restrict__ vt_slab, int skv_pad) {
+    __shared__ uint16_t tile[64][130];
+    __shared__ size_t dpos[64];
+    const int tid = threadIdx.x, m0 = blockIdx.x * 64, h = blockIdx.y;
+    // load: 64 rows x 256 B, 16 B per thread per pass
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = (tid >> 4) + it * 16, c = (tid & 15) * 8;
+        const int m = min(m0 + r, M - 1);
+        uint16_t t[8];
+        *(uint4*)t = *(const uint4*)(qkv + (size_t)m * ld + v_col + h * 128 + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[r][c + e] = t[e];
+    }
+    if (tid < 64) {
+        const int m = m0 + tid;
+        dpos[tid] = (m < M) ? kvpos(kv_rows ? (size_t)kv_rows[m] : (size_t)m) : (size_t)-1;
+    }
+    __syncthreads();
+    const int r = tid & 63;
+    const size_t p = dpos[r];
+    if (p == (size_t)-1) return;
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+        const int dd = (tid >> 6) + it * 4;
+        vt_slab[((size_t)h * 128 + dd) * skv_pad + p] = tile[r][dd];
+    }
+}
+
+}  // namespace rgn
+
+using namespace rgn;
+
+extern "C" {
+
+int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int split_row,
+                    const void* shift0, const void* scale0, const void* shift1, const void* scale1, void* stream) {
+    if (M == 0) return 0;
+    if (!x || !out || M < 0 || d <= 0 || (d % 8) || d > 8192 || (ldx % 8) || (ldo % 8) || !shift1 || !scale1)
+        return fail(RGN_E_BADARG, "ln_modulate: bad argument");
+    if (split_row > 0 && (!shift0 || !scale0)) return fail(RGN_E_BADARG, "ln_modulate: stream-0 modulation missing");
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+                       (uint16_t*)out, ldo, d, eps, split_row, (const uint16_t*)shift0, (const uint16_t*)scale0,
+                       (const uint16_t*)shift1, (const uint16_t*)scale1);
+    return check_launch("ln_modulate_kernel");
+}
+
+int rgn_qk_norm_rope_store(void* qkv, int ld, int k_col, int v_col, int q_col, int M, int H, int split_row,
+                           const void* wq0, const void* wk0, const void* wq1, const void* wk1, float eps,
+                           const float* cos_q, const float* sin_q, const float* cos_k, const float* sin_k,
+                           const int64_t* kv_rows, void* k_slab, void* vt_slab, int skv_pad, void* stream) {
+    if (M == 0) return 0;
+    if (!qkv || !wq1 || !wk1 || !cos_q || !sin_q || !cos_k || !sin_k || !k_slab || !vt_slab || M < 0 || H <= 0 ||
+        (ld % 8) || (k_col % 8) || (v_col % 8) || (q_col % 8) || (skv_pad % 64))
+        return fail(RGN_E_BADARG, "qk_norm_rope_store: bad argument");
+    if (split_row > 0 && (!wq0 || !wk0)) return fail(RGN_E_BADARG, "qk_norm_rope_store: stream-0 norm weights missing");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((M + 3) / 4), dim3(256), 0, st, (uint16_t*)qkv, ld, k_col, q_col, M, H,
+                       split_row, (const uint16_t*)wq0, (const uint16_t*)wk0, (const uint16_t*)wq1,
+                       (const uint16_t*)wk1, eps, cos_q, sin_q, cos_k, sin_k, kv_rows, (uint16_t*)k_slab);
+    int rc = check_launch("qk_norm_rope_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(v_transpose_store_kernel, dim3((M + 63) / 64, H), dim3(256), 0, st, (const uint16_t*)qkv, ld,
+                       v_col, M, kv_rows, (uint16_t*)vt_slab, skv_pad);
+    return check_launch("v_transpose_store_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+"""Tensor-level wrappers over the C ABI (include/regione_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every arithmetic op of the hot
+path runs in libregione_hip.so.  Wrappers pass raw device pointers + the current stream; they never
+synchronise except where a host-visible count is explicitly requested.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_GATE_RESID = 0, 1, 2
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype} (fp32 / bf16 only)")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.RegionEHipError("regione_amd ops need CUDA/HIP tensors: there is no CPU fallback")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """[1,L,D] or [L,D] -> contiguous [L,D] view."""
+    if t.dim() == 3:
+        assert t.shape[0] == 1, "region ops are per image (reference is batch-1, quirk A-5)"
+        t = t[0]
+    assert t.is_contiguous()
+    return t
+
+
+def padded(n: int, m: int = 64) -> int:
+    return (n + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------
+# region ops
+# ---------------------------------------------------------------------------------------------
+def arp_partition(sample: torch.Tensor, model_output: Optional[torch.Tensor], cond: torch.Tensor,
+                  dt_final: float, threshold: float, h_tok: int, w_tok: int, erosion_dilation: bool = True,
+                  want_sim: bool = False):
+    """token_selector + one-step estimate.  Returns (edited_ids i64[1,K], unedited_ids i64[1,L-K],
+    mask u8[L], raw u8[L], sim f32[L] or None).  ONE 4-byte D2H read (K_e) - the only host sync the
+    partition needs; every later launch of the image is shape-static."""
+    s, c = _rows(sample), _rows(cond)
+    mo = _rows(model_output) if model_output is not None else None
+    L, D = s.shape
+    dev = s.device
+    e = torch.empty(L, dtype=torch.int64, device=dev)
+    u = torch.empty(L, dtype=torch.int64, device=dev)
+    raw = torch.empty(L, dtype=torch.uint8, device=dev)
+    mask = torch.empty(L, dtype=torch.uint8, device=dev)
+    sim = torch.empty(L, dtype=torch.float32, device=dev) if want_sim else None
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().rgn_arp_partition(_p(s), _dt(s), _p(mo), _dt(mo) if mo is not None else F32, _p(c), _dt(c),
+                                      float(dt_final), float(threshold), L, D, h_tok, w_tok, int(erosion_dilation),
+                                      _p(e), _p(u), _p(raw), _p(mask), _p(sim), _p(cnt), _stream())
+    _lib.check(rc, "rgn_arp_partition")
+    k = int(cnt.item())
+    return e[:k].unsqueeze(0), u[: L - k].unsqueeze(0), mask, raw, sim
+
+
+def morph_compact(raw_mask: torch.Tensor, erosion_dilation: bool = True):
+    h, w = raw_mask.shape
+    L = h * w
+    dev = raw_mask.device
+    e = torch.empty(L, dtype=torch.int64, device=dev)
+    u = torch.empty(L, dtype=torch.int64, device=dev)
+    mask = torch.empty(L, dtype=torch.uint8, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    rc = _lib.lib().rgn_morph_compact(_p(raw_mask.contiguous()), h, w, int(erosion_dilation), _p(e), _p(u), _p(mask),
+                                      _p(cnt), _stream())
+    _lib.check(rc, "rgn_morph_compact")
+    k = int(cnt.item())
+    return e[:k], u[: L - k], mask.view(h, w)
+
+
+def gather_rows(x: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """ids_gather for [1,L,D] x, [1,K] ids -> [1,K,D]."""
+    src = _rows(x)
+    idv = ids.reshape(-1).contiguous()
+    K = idv.numel()
+    out = torch.empty((K, src.shape[1]), dtype=src.dtype, device=src.device)
+    rc = _lib.lib().rgn_gather_rows(_p(src), _p(idv), _p(out), K, src.shape[1] * src.element_size(), _stream())
+    _lib.check(rc, "rgn_gather_rows")
+    return out.unsqueeze(0) if x.dim() == 3 else out
+
+
+def scatter_rows_(src: torch.Tensor, ids: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """ids_scatter: dst[ids[k]] = src[k] in place; returns dst."""
+    s, d = _rows(src), _rows(dst)
+    idv = ids.reshape(-1).contiguous()
+    rc = _lib.lib().rgn_scatter_rows(_p(s), _p(idv), _p(d), idv.numel(), s.shape[1] * s.element_size(), _stream())
+    _lib.check(rc, "rgn_scatter_rows")
+    return dst
+
+
+def euler_step(sample: torch.Tensor, v: torch.Tensor, dt: float, mask: Optional[torch.Tensor] = None,
+               dt_direct: float = 0.0) -> torch.Tensor:
+    s, vv = _rows(sample), _rows(v)
+    out = torch.empty_like(vv)
+    rc = _lib.lib().rgn_euler_step(_p(s), _dt(s), _p(vv), _dt(vv), _p(out), _p(mask), float(dt), float(dt_direct),
+                                   s.shape[0], s.shape[1], _stream())
+    _lib.check(rc, "rgn_euler_step")
+    return out.unsqueeze(0) if v.dim() == 3 else out
+
+
+def avd_apply(cache: torch.Tensor, ratio: float, ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+    c = _rows(cache)
+    idv = ids.reshape(-1).contiguous() if ids is not None else None
+    K = idv.numel() if idv is not None else c.shape[0]
+    out = torch.empty((K, c.shape[1]), dtype=c.dtype, device=c.device)
+    rc = _lib.lib().rgn_avd_apply(_p(c), _dt(c), _p(idv), float(ratio), _p(out), K, c.shape[1], _stream())
+    _lib.check(rc, "rgn_avd_apply")
+    return out.unsqueeze(0) if cache.dim() == 3 else out
+
+
+# ---------------------------------------------------------------------------------------------
+# MMDiT block kernels
+# ---------------------------------------------------------------------------------------------
+def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, epilogue: int = EPI_BIAS,
+         gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+         out_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[r] = epilogue(A @ W^T + bias).  A [M,K] (row stride may exceed K), W [N,K], out [*,N] view."""
+    assert A.dtype == W.dtype == out.dtype == torch.bfloat16
+    M, K = A.shape
+    N = W.shape[0]
+    assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and W.shape[1] == K and out.shape[1] == N
+    if resid is not None:
+        assert resid.stride(0) == out.stride(0) and resid.stride(1) == 1
+    rc = _lib.lib().rgn_gemm_bf16(_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                  epilogue, gelu_from_col, _p(gate), _p(resid), _p(out_rows), _stream())
+    _lib.check(rc, "rgn_gemm_bf16")
+    return out
+
+
+def gemv(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], silu_input: bool = False,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, K = x.shape
+    N = W.shape[0]
+    assert W.is_contiguous() and x.stride(1) == 1
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.bfloat16, device=x.device)
+    rc = _lib.lib().rgn_gemv_bf16(_p(x), x.stride(0), _p(W), _p(bias), _p(out), out.stride(0), B, N, K,
+                                  int(silu_input), _stream())
+    _lib.check(rc, "rgn_gemv_bf16")
+    return out
+
+
+def ln_modulate(x: torch.Tensor, out: torch.Tensor, shift1, scale1, split_row: int = 0, shift0=None, scale0=None,
+                eps: float = 1e-6) -> torch.Tensor:
+    M, d = x.shape
+    rc = _lib.lib().rgn_ln_modulate(_p(x), x.stride(0), _p(out), out.stride(0), M, d, eps, split_row, _p(shift0),
+                                    _p(scale0), _p(shift1), _p(scale1), _stream())
+    _lib.check(rc, "rgn_ln_modulate")
+    return out
+
+
+def qk_norm_rope_store(qkv: torch.Tensor, k_col: int, v_col: int, q_col: int, H: int, wq1, wk1, rope_q, rope_k,
+                       k_slab: torch.Tensor, vt_slab: torch.Tensor, kv_rows: Optional[torch.Tensor] = None,
+                       split_row: int = 0, wq0=None, wk0=None, eps: float = 1e-6):
+    M = qkv.shape[0]
+    skv_pad = k_slab.shape[0]
+    assert vt_slab.shape == (H * 128, skv_pad) and k_slab.shape[1] == H * 128
+    rc = _lib.lib().rgn_qk_norm_rope_store(_p(qkv), qkv.stride(0), k_col, v_col, q_col, M, H, split_row, _p(wq0),
+                                           _p(wk0), _p(wq1), _p(wk1), eps, _p(rope_q[0]), _p(rope_q[1]),
+                                           _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows), _p(k_slab), _p(vt_slab), skv_pad,
+                                           _stream())
+    _lib.check(rc, "rgn_qk_norm_rope_store")
+
+
+def attention(q: torch.Tensor, k_slab: torch.Tensor, vt_slab: torch.Tensor, out: torch.Tensor, skv: int, H: int,
+              scale: Optional[float] = None) -> torch.Tensor:
+    """q / out: [Sq, H*128] views (row stride free, may alias)."""
+    Sq = q.shape[0]
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    rc = _lib.lib().rgn_attention(_p(q), q.stride(0), _p(k_slab), _p(vt_slab), k_slab.shape[0], _p(out), out.stride(0),
+                                  Sq, skv, H, float(scale), _stream())
+    _lib.check(rc, "rgn_attention")
+    return out
+
+
+def device_info() -> Tuple[int, int, int]:
+    import ctypes as C
+    cu, clk, mem = C.c_int(), C.c_int(), C.c_size_t()
+    _lib.check(_lib.lib().rgn_device_info(C.byref(cu), C.byref(clk), C.byref(mem)), "rgn_device_info")
+    return cu.value, clk.value, mem.value

@@ -1,0 +1,181 @@
+"""-m gpu: MMDiT block kernels (through the C ABI) vs torch-CPU fp32 references of the same op.
+Floating point: tolerances are stated per test; bf16 outputs are compared after the same rounding
+points as the eager bf16 sequence, so most results agree to <= 1 bf16 ulp."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import regione_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 256, 192), (1, 128, 64), (1000, 64, 3072),
+                                   (777, 200, 128), (8704, 3072, 3072)])
+def test_gemm_bias(M, N, K):
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    # asymmetric operands so a transposed C-write cannot pass (guide rule 16)
+    A = bf(torch.randn(M, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    b = bf(torch.randn(N, generator=g))
+    out = torch.zeros(M, N, dtype=torch.bfloat16).cuda()
+    ops.gemm(A.cuda(), W.cuda(), b.cuda(), out)
+    if M * N * K <= 2 ** 31:
+        ref = (A.double() @ W.double().T + b.double())
+    else:
+        ref = (A.cuda().float() @ W.cuda().float().T + b.cuda().float()).cpu().double()
+    err = (out.cpu().double() - ref).abs()
+    tol = 2 ** -8 * ref.abs() + 1e-2           # one bf16 rounding of the result + fp32 accumulation noise
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert rel_err(out.cpu(), ref) < 3e-3
+
+
+def test_gemm_strided_views_scatter_and_epilogues():
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 200, 256, 128
+    big = bf(torch.randn(M, 512, generator=g)).cuda()
+    A = big[:, 128:256]                                           # lda = 512
+    W = bf(torch.randn(N, K, generator=g) * 0.1).cuda()
+    b = bf(torch.randn(N, generator=g)).cuda()
+    # GELU from a column
+    outbuf = torch.zeros(M, 640, dtype=torch.bfloat16).cuda()
+    out = outbuf[:, 64:64 + N]                                    # ldc = 640
+    ops.gemm(A, W, b, out, epilogue=ops.EPI_GELU, gelu_from_col=128)
+    lin = bf(F.linear(A.cpu().float(), W.cpu().float(), b.cpu().float()))
+    ref = lin.clone()
+    ref[:, 128:] = F.gelu(lin[:, 128:], approximate="tanh")
+    assert rel_err(out.cpu(), ref) < 4e-3
+    assert float((out.cpu().float() - ref.float()).abs().max()) <= 2 ** -6 * float(ref.float().abs().max())
+    assert float(outbuf[:, :64].abs().max()) == 0 and float(outbuf[:, 64 + N:].abs().max()) == 0
+    # gated residual in place
+    resid = bf(torch.randn(M, N, generator=g)).cuda()
+    gate = bf(torch.randn(N, generator=g)).cuda()
+    r0 = resid.clone()
+    ops.gemm(A, W, b, resid, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=resid)
+    ref = r0.cpu() + gate.cpu().unsqueeze(0) * lin
+    assert rel_err(resid.cpu(), ref) < 4e-3
+    # row scatter (the _partially_linear replacement, fused_kernels.py:77-80)
+    cache = bf(torch.randn(1000, N, generator=g)).cuda()
+    c0 = cache.clone().cpu()
+    idx = torch.randperm(1000, generator=g)[:M].sort().values
+    ops.gemm(A, W, b, cache, out_rows=idx.cuda())
+    ref = O.partially_linear(A.cpu().unsqueeze(0), W.cpu(), b.cpu(), idx, c0.unsqueeze(0).clone(), fp16_roundtrip=False)[0]
+    untouched = torch.ones(1000, dtype=torch.bool)
+    untouched[idx] = False
+    assert torch.equal(cache.cpu()[untouched], c0[untouched])
+    assert rel_err(cache.cpu()[idx], ref[idx]) < 3e-3
+
+
+@pytest.mark.parametrize("B,N,K,silu", [(1, 18432, 3072, True), (2, 1000, 256, False), (1, 3072, 768, False)])
+def test_gemv(B, N, K, silu):
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(B + N)
+    x = bf(torch.randn(B, K, generator=g))
+    W = bf(torch.randn(N, K, generator=g) * 0.05)
+    b = bf(torch.randn(N, generator=g))
+    y = ops.gemv(x.cuda(), W.cuda(), b.cuda(), silu_input=silu)
+    xin = F.silu(x) if silu else x
+    ref = F.linear(xin.double(), W.double(), b.double())
+    assert rel_err(y.cpu(), ref) < 3e-3
+
+
+@pytest.mark.parametrize("d", [256, 3072])
+def test_ln_modulate(d):
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(d)
+    M, T = 300, 40
+    x = bf(torch.randn(M, d, generator=g) * 2 + 0.3)
+    mods = [bf(torch.randn(1, d, generator=g) * 0.5) for _ in range(4)]
+    out = torch.empty(M, d, dtype=torch.bfloat16).cuda()
+    ops.ln_modulate(x.cuda(), out, mods[2].cuda(), mods[3].cuda(), split_row=T, shift0=mods[0].cuda(), scale0=mods[1].cuda())
+    ref = torch.empty_like(x)
+    ref[:T] = O.layer_norm(x[:T]) * (1 + mods[1]) + mods[0]
+    ref[T:] = O.layer_norm(x[T:]) * (1 + mods[3]) + mods[2]
+    diff = (out.cpu().float() - ref.float()).abs()
+    assert float(diff.max()) <= 2 ** -6 * float(ref.float().abs().max())        # <= ~2 bf16 ulp at the largest magnitude
+    assert float((diff > 0).float().mean()) < 0.02                               # and almost always bit-identical
+
+
+def test_qk_norm_rope_store_and_attention_vs_reference_processor_math():
+    """Whole attention path of a single-stream block at toy size: raw [k|v|q] projections ->
+    RMSNorm/RoPE/store -> region attention, against the oracle's processor math
+    (RegionE/FluxKontext/inplace.py:754-806)."""
+    from regione_amd import ops
+    from regione_amd import synth
+    g = torch.Generator().manual_seed(11)
+    H, T, h_tok, w_tok = 2, 32, 16, 16
+    N = 2 * h_tok * w_tok
+    S = T + N                                                       # 544: not a multiple of 64 -> tail mask
+    D = H * 128
+    raw = bf(torch.randn(S, 3 * D, generator=g))
+    wq, wk = bf(1 + 0.1 * torch.randn(128, generator=g)), bf(1 + 0.1 * torch.randn(128, generator=g))
+    ids = torch.cat([torch.zeros(T, 3), synth.flux_latent_ids(h_tok, w_tok)], 0)
+    cos, sin = O.flux_pos_embed(ids)
+    skv_pad = ops.padded(S)
+    k_slab = torch.zeros(skv_pad, D, dtype=torch.bfloat16).cuda()
+    vt_slab = torch.zeros(D, skv_pad, dtype=torch.bfloat16).cuda()
+    buf = raw.cuda().clone()
+    rope = (cos.cuda(), sin.cuda())
+    ops.qk_norm_rope_store(buf, 0, D, 2 * D, H, wq.cuda(), wk.cuda(), rope, rope, k_slab, vt_slab)
+    # reference
+    k = raw[:, :D].view(1, S, H, 128).transpose(1, 2)
+    v = raw[:, D:2 * D].view(1, S, H, 128).transpose(1, 2)
+    q = raw[:, 2 * D:].view(1, S, H, 128).transpose(1, 2)
+    qn = O.apply_rope(O.rms_norm(q, wq), cos, sin)
+    kn = O.apply_rope(O.rms_norm(k, wk), cos, sin)
+    q_out = buf[:, 2 * D:].cpu().view(S, H, 128).transpose(0, 1)
+    assert float((q_out.float() - qn[0].float()).abs().max()) <= 2 ** -7 * float(qn.float().abs().max())
+    assert float((q_out != qn[0]).float().mean()) < 0.01
+    k_out = k_slab[:S].cpu().view(S, H, 128).transpose(0, 1)
+    assert float((k_out != kn[0]).float().mean()) < 0.01
+    # V^T slab: column kvpos(r) holds row r
+    r = torch.arange(S)
+    pos = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+    vt = vt_slab.cpu()[:, pos]                                      # [D, S]
+    assert torch.equal(vt.view(H, 128, S).permute(0, 2, 1), v[0])
+    # attention over a compacted query subset (Sq != Skv)
+    sel = torch.cat([torch.arange(T), T + torch.randperm(N, generator=g)[:100].sort().values])
+    qbuf = buf[:, 2 * D:][sel.cuda()].contiguous()
+    out = torch.empty_like(qbuf)
+    ops.attention(qbuf, k_slab, vt_slab, out, S, H)
+    ref = F.scaled_dot_product_attention(qn[:, :, sel].float(), kn.float(), v.float())
+    ref = ref.transpose(1, 2).reshape(len(sel), D)
+    assert rel_err(out.cpu(), ref) < 1e-2
+    assert float((out.cpu().float() - ref).abs().max()) < 2e-2 * float(ref.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("Sq,Skv,H", [(128, 64, 1), (200, 1000, 3), (1536, 8704, 24)])
+def test_attention_shapes(Sq, Skv, H):
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(Sq + Skv)
+    D = H * 128
+    q = bf(torch.randn(Sq, D, generator=g))
+    k = bf(torch.randn(Skv, D, generator=g))
+    v = bf(torch.randn(Skv, D, generator=g))
+    k[5] *= 6.0                                                       # a spiky key forces a late running-max jump
+    pad = ops.padded(Skv)
+    ks = torch.zeros(pad, D, dtype=torch.bfloat16)
+    ks[:Skv] = k
+    r = torch.arange(Skv)
+    pos = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+    vt = torch.zeros(D, pad, dtype=torch.bfloat16)
+    vt[:, pos] = v.T
+    out = torch.empty(Sq, D, dtype=torch.bfloat16).cuda()
+    ops.attention(q.cuda(), ks.cuda(), vt.cuda(), out, Skv, H)
+    dev = "cuda" if Sq * Skv * H > 5e6 else "cpu"
+    qq, kk, vv = (t.to(dev).float().view(-1, H, 128).transpose(0, 1) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qq[None], kk[None], vv[None])[0].transpose(0, 1).reshape(Sq, D).cpu()
+    assert rel_err(out.cpu(), ref) < 1e-2
