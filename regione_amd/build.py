@@ -12,6 +12,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libregione_hip.so")
 SOURCES = ["region.hip", "gemm.hip", "norm.hip", "attn.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+# region / norm kernels mirror eager op sequences rounding-for-rounding: a*b+c must NOT contract to fma
+EXTRA = {"region.hip": ["-ffp-contract=off"], "norm.hip": ["-ffp-contract=off"]}
 
 
 def _stale() -> bool:
@@ -35,7 +37,7 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
         if not os.path.exists(src):
             raise FileNotFoundError(src)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

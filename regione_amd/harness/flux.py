@@ -1,0 +1,532 @@
+"""Self-contained FLUX.1-Kontext-shaped pipeline harness on the HIP kernels.
+
+`diffusers` is not installable in this image, so the four hook points the
+reference patches (RegionE/FluxKontext/inplace.py:53-62) are provided by this module with the same
+names and call signatures:
+
+    pipeline.__class__            FluxKontextPipeline.__call__           (denoise loop)
+    pipeline.scheduler            FlowMatchEulerDiscreteScheduler.step
+    pipeline.transformer.forward  FluxTransformer2DModel.forward
+    block.attn.set_processor(p)   p(attn, hidden_states, encoder_hidden_states=None,
+                                    attention_mask=None, image_rotary_emb=None)
+
+Everything below [EXT] restates upstream diffusers semantics (the reference only *calls* them) on
+top of regione_amd.ops; the MMDiT arithmetic itself runs in libregione_hip.so.  There is no torch
+fallback: tensors must live on the GPU.
+
+Engine layout (one image, B = 1):
+  * the residual stream is ONE buffer x = [text rows ; image rows] ([T+M, d]) for double AND single
+    blocks, so the double->single transition needs no concat;
+  * QKV(+MLP) projections land in one wide buffer with column blocks [k | v | q | mlp]; attention
+    writes its output over q, so `cat([attn, mlp])` (single block) is just a column view;
+  * K is cached post-RMSNorm/post-RoPE and V transposed (see rgn_qk_norm_rope_store): mathematically
+    identical to the reference's raw cache because both ops are row-wise with fixed positions
+    (SURVEY.md section 7 hard-part 3), and it removes the per-step re-normalisation of all T+N rows;
+  * all AdaLN modulation vectors of all 57 layers come from ONE HBM-bound GEMV per step.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..synth import FluxConfig
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+    def get(self, k, default=None):  # noqa: D401 - dict.get with attribute access
+        return dict.get(self, k, default)
+
+
+# ---------------------------------------------------------------------------------------------
+# [EXT] scheduler base
+# ---------------------------------------------------------------------------------------------
+class FlowMatchEulerDiscreteScheduler:
+    """[EXT] FlowMatchEulerDiscreteScheduler (dynamic exponential shifting).  sigmas / timesteps are
+    kept on the HOST (fp32 torch-CPU tensors): every dt the loop needs is host arithmetic with the
+    reference's fp32 rounding and costs no device sync."""
+
+    order = 1
+
+    def __init__(self, **config):
+        cfg = dict(num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
+                   base_image_seq_len=256, max_image_seq_len=4096, stochastic_sampling=False)
+        cfg.update(config)
+        self.config = _Cfg(cfg)
+        self.sigmas = None
+        self.timesteps = None
+        self._step_index = None
+        self._begin_index = None
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(**dict(config))
+
+    @property
+    def step_index(self):
+        return self._step_index
+
+    def set_begin_index(self, begin_index: int = 0):
+        self._begin_index = begin_index
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        if sigmas is None:
+            sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        sigmas = np.array(sigmas).astype(np.float32)
+        if self.config.use_dynamic_shifting:
+            sigmas = math.exp(mu) / (math.exp(mu) + (1 / sigmas - 1) ** 1.0)
+        else:
+            s = self.config.shift
+            sigmas = s * sigmas / (1 + (s - 1) * sigmas)
+        sigmas = torch.from_numpy(np.asarray(sigmas, dtype=np.float32))
+        self.timesteps = sigmas * self.config.num_train_timesteps
+        self.sigmas = torch.cat([sigmas, torch.zeros(1)])
+        self.num_inference_steps = len(self.timesteps)
+        self._step_index = None
+
+    def _init_step_index(self, timestep):
+        if self._begin_index is None:
+            idx = (self.timesteps == timestep).nonzero()
+            self._step_index = idx[1 if len(idx) > 1 else 0].item()
+        else:
+            self._step_index = self._begin_index
+
+    def step(self, model_output, timestep, sample, return_dict: bool = True, **kw):
+        if isinstance(timestep, int) or (isinstance(timestep, torch.Tensor) and not timestep.is_floating_point()):
+            raise ValueError("Passing integer indices (e.g. from `enumerate(timesteps)`) as timesteps to"
+                             " `FlowMatchEulerDiscreteScheduler.step()` is not supported.")
+        if self._step_index is None:
+            self._init_step_index(timestep)
+        i = self._step_index
+        dt = float(self.sigmas[i + 1] - self.sigmas[i])
+        prev = ops.euler_step(sample, model_output, dt)
+        self._step_index += 1
+        return (prev,) if not return_dict else _Cfg(prev_sample=prev)
+
+
+# ---------------------------------------------------------------------------------------------
+# [EXT] rotary table (host, float64 angles like diffusers' FluxPosEmbed)
+# ---------------------------------------------------------------------------------------------
+class FluxPosEmbed:
+    def __init__(self, theta=10000, axes_dim=(16, 56, 56)):
+        self.theta, self.axes_dim = theta, tuple(axes_dim)
+        self._cache: Dict[Tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def __call__(self, ids: torch.Tensor, device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+        ids = ids.detach().cpu()
+        key = (ids.shape[0], hash(ids.numpy().tobytes()))
+        if key not in self._cache:
+            cos_out, sin_out = [], []
+            pos = ids.float()
+            for i, dim in enumerate(self.axes_dim):
+                freqs = 1.0 / (self.theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
+                ang = torch.outer(pos[:, i].to(torch.float64), freqs)
+                cos_out.append(ang.cos().repeat_interleave(2, dim=1).float())
+                sin_out.append(ang.sin().repeat_interleave(2, dim=1).float())
+            if len(self._cache) > 8:
+                self._cache.clear()
+            self._cache[key] = (torch.cat(cos_out, -1).contiguous().to(device), torch.cat(sin_out, -1).contiguous().to(device))
+        return self._cache[key]
+
+
+def timestep_embedding(t: torch.Tensor, dim=256, max_period=10000) -> torch.Tensor:
+    """[EXT] get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0); host, fp32."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    a = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# workspace + modulation
+# ---------------------------------------------------------------------------------------------
+class Workspace:
+    """Activation buffers shared by all blocks of one transformer (grown on demand, never per step)."""
+
+    def __init__(self, cfg: FluxConfig, device):
+        self.cfg, self.device = cfg, device
+        self.rows = 0
+        self.skv_pad = 0
+
+    def ensure(self, rows: int, skv: int):
+        d, ff = self.cfg.d, self.cfg.d * self.cfg.mlp_ratio
+        if rows > self.rows:
+            kw = dict(dtype=torch.bfloat16, device=self.device)
+            self.x = torch.empty(rows, d, **kw)
+            self.nrm = torch.empty(rows, d, **kw)
+            self.wide = torch.empty(rows, 3 * d + ff, **kw)        # [k | v | q | mlp]
+            self.rows = rows
+        pad = ops.padded(skv)
+        if pad > self.skv_pad:
+            kw = dict(dtype=torch.bfloat16, device=self.device)
+            self.k_scratch = torch.zeros(pad, d, **kw)            # zero-filled: pad rows must stay finite
+            self.vt_scratch = torch.zeros(d, pad, **kw)
+            self.skv_pad = pad
+
+
+class Modulation:
+    """All AdaLN vectors of one forward: `vec` = [1, total] bf16 = linear(silu(temb)) of every block."""
+
+    def __init__(self, vec: torch.Tensor, d: int):
+        self.vec, self.d = vec, d
+
+    def chunk(self, offset: int, i: int) -> torch.Tensor:
+        return self.vec[0, offset + i * self.d: offset + (i + 1) * self.d]
+
+
+class FwdCtx:
+    """Per-forward context handed to the processors alongside the reference's arguments."""
+
+    def __init__(self, ws: Workspace, T: int, M: int, mods: Modulation):
+        self.ws, self.T, self.M, self.mods = ws, T, M, mods
+
+
+# ---------------------------------------------------------------------------------------------
+# [EXT] module tree
+# ---------------------------------------------------------------------------------------------
+class Attention:
+    """Weight container + processor slot (diffusers.models.attention_processor.Attention)."""
+
+    def __init__(self, heads: int, head_dim: int):
+        self.heads, self.head_dim = heads, head_dim
+        self.processor = None
+
+    def set_processor(self, processor):
+        self.processor = processor
+
+    def __call__(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **kw)
+
+
+class FluxAttnProcessor:
+    """Vanilla (full-token) attention processor: plain K/V into the shared scratch slab."""
+
+    def __init__(self, single: bool = False):
+        self.single = single
+
+    # -- the three K/V destinations ---------------------------------------------------------------
+    def kv_target(self, attn: Attention, ctx: FwdCtx):
+        """-> (k_slab, vt_slab, kv_rows, skv, rope_k).  Vanilla: scratch slab, identity rows."""
+        ws = ctx.ws
+        return ws.k_scratch, ws.vt_scratch, None, ctx.T + ctx.M, None
+
+    def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None,
+                 image_rotary_emb=None, ctx: FwdCtx = None, block=None):
+        ws, T, M, d, H = ctx.ws, ctx.T, ctx.M, attn.heads * attn.head_dim, attn.heads
+        R = T + M
+        wide = ws.wide[:R]
+        k_slab, vt_slab, kv_rows, skv, rope_k = self.kv_target(attn, ctx)
+        rope_k = rope_k if rope_k is not None else image_rotary_emb
+        if not self.single:
+            ops.gemm(ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d])
+            ops.gemm(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d])
+            ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
+                                   k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
+            q = wide[:, 2 * d:3 * d]
+            ops.attention(q, k_slab, vt_slab, q, skv, H)
+            g_img, g_txt = block.gates_msa(ctx)
+            ops.gemm(q[T:R], attn.w_out, attn.b_out, ws.x[T:R], epilogue=ops.EPI_GATE_RESID, gate=g_img, resid=ws.x[T:R])
+            ops.gemm(q[:T], attn.w_add_out, attn.b_add_out, ws.x[:T], epilogue=ops.EPI_GATE_RESID, gate=g_txt,
+                     resid=ws.x[:T])
+            return ws.x[T:R], ws.x[:T]
+        # single stream: one GEMM produces [k | v | q | gelu(mlp)] from the same normed activations
+        ops.gemm(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * d)
+        ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
+                               vt_slab, kv_rows)
+        q = wide[:, 2 * d:3 * d]
+        ops.attention(q, k_slab, vt_slab, q, skv, H)
+        return wide[:, 2 * d:]                                       # cat([attn_output, mlp_hidden], dim=2)
+
+
+class FluxTransformerBlock:
+    """[EXT] FluxTransformerBlock (double stream) on the shared workspace."""
+
+    def __init__(self, cfg: FluxConfig, mod_offset_img: int, mod_offset_ctx: int):
+        self.attn = Attention(cfg.heads, cfg.head_dim)
+        self.attn.set_processor(FluxAttnProcessor(False))
+        self.mo_img, self.mo_ctx = mod_offset_img, mod_offset_ctx
+
+    def gates_msa(self, ctx: FwdCtx):
+        return ctx.mods.chunk(self.mo_img, 2), ctx.mods.chunk(self.mo_ctx, 2)
+
+    def __call__(self, hidden_states, encoder_hidden_states, temb: FwdCtx, image_rotary_emb=None,
+                 joint_attention_kwargs=None):
+        ctx = temb
+        ws, T, M, mods = ctx.ws, ctx.T, ctx.M, ctx.mods
+        R = T + M
+        d = ws.cfg.d
+        # norm1 / norm1_context: LN * (1 + scale_msa) + shift_msa   (chunks: shift, scale, gate, shift, scale, gate)
+        ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo_img, 0), mods.chunk(self.mo_img, 1), split_row=T,
+                        shift0=mods.chunk(self.mo_ctx, 0), scale0=mods.chunk(self.mo_ctx, 1))
+        self.attn(hidden_states=ws.nrm[T:R], encoder_hidden_states=ws.nrm[:T], image_rotary_emb=image_rotary_emb,
+                  ctx=ctx, block=self)
+        # norm2 + FF with the gated residual fused into the second GEMM
+        ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo_img, 3), mods.chunk(self.mo_img, 4), split_row=T,
+                        shift0=mods.chunk(self.mo_ctx, 3), scale0=mods.chunk(self.mo_ctx, 4))
+        ffh = ws.wide[:R, 3 * d:]
+        ops.gemm(ws.nrm[T:R], self.ff_w1, self.ff_b1, ffh[T:R], epilogue=ops.EPI_GELU)
+        ops.gemm(ffh[T:R], self.ff_w2, self.ff_b2, ws.x[T:R], epilogue=ops.EPI_GATE_RESID,
+                 gate=mods.chunk(self.mo_img, 5), resid=ws.x[T:R])
+        ops.gemm(ws.nrm[:T], self.ffc_w1, self.ffc_b1, ffh[:T], epilogue=ops.EPI_GELU)
+        ops.gemm(ffh[:T], self.ffc_w2, self.ffc_b2, ws.x[:T], epilogue=ops.EPI_GATE_RESID,
+                 gate=mods.chunk(self.mo_ctx, 5), resid=ws.x[:T])
+        return ws.x[:T], ws.x[T:R]
+
+
+class FluxSingleTransformerBlock:
+    """[EXT] FluxSingleTransformerBlock on the shared workspace."""
+
+    def __init__(self, cfg: FluxConfig, mod_offset: int):
+        self.attn = Attention(cfg.heads, cfg.head_dim)
+        self.attn.set_processor(FluxAttnProcessor(True))
+        self.mo = mod_offset
+
+    def __call__(self, hidden_states, encoder_hidden_states, temb: FwdCtx, image_rotary_emb=None,
+                 joint_attention_kwargs=None):
+        ctx = temb
+        ws, T, M, mods = ctx.ws, ctx.T, ctx.M, ctx.mods
+        R = T + M
+        ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo, 0), mods.chunk(self.mo, 1))
+        cat = self.attn(hidden_states=ws.nrm[:R], image_rotary_emb=image_rotary_emb, ctx=ctx, block=self)
+        ops.gemm(cat, self.w_po, self.b_po, ws.x[:R], epilogue=ops.EPI_GATE_RESID, gate=mods.chunk(self.mo, 2),
+                 resid=ws.x[:R])
+        return ws.x[:T], ws.x[T:R]
+
+
+class FluxTransformer2DModel:
+    """[EXT] module tree of diffusers' FluxTransformer2DModel with HIP-backed blocks."""
+
+    def __init__(self, cfg: FluxConfig, device="cuda"):
+        self.cfg_model = cfg
+        self.config = _Cfg(in_channels=cfg.in_channels, guidance_embeds=True)
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16
+        self.gradient_checkpointing = False
+        self.pos_embed = FluxPosEmbed(10000, cfg.axes_dim)
+        d = cfg.d
+        off = 0
+        self.transformer_blocks: List[FluxTransformerBlock] = []
+        for _ in range(cfg.n_double):
+            self.transformer_blocks.append(FluxTransformerBlock(cfg, off, off + 6 * d))
+            off += 12 * d
+        self.single_transformer_blocks: List[FluxSingleTransformerBlock] = []
+        for _ in range(cfg.n_single):
+            self.single_transformer_blocks.append(FluxSingleTransformerBlock(cfg, off))
+            off += 3 * d
+        self.mo_out = off
+        self.mod_total = off + 2 * d
+        self.ws = Workspace(cfg, self.device)
+        self._temb_cache: Dict[Tuple, torch.Tensor] = {}
+
+    # -- weights ------------------------------------------------------------------------------------
+    def load_state_dict_stream(self, items):
+        """Consume (name, tensor) pairs in diffusers FLUX naming (any order inside a block) and build
+        the fused layouts.  Originals are dropped as soon as a fused tensor is complete, so the 12 B
+        parameter model peaks at ~1x its size."""
+        dev, cfg, d = self.device, self.cfg_model, self.cfg_model.d
+        pend: Dict[str, torch.Tensor] = {}
+        mod_w = torch.empty(self.mod_total, d, dtype=torch.bfloat16, device=dev)
+        mod_b = torch.empty(self.mod_total, dtype=torch.bfloat16, device=dev)
+        self.mod_w, self.mod_b = mod_w, mod_b
+
+        def take(name):
+            return pend.pop(name).to(dev, torch.bfloat16)
+
+        def try_finish():
+            # double blocks
+            for i, blk in enumerate(self.transformer_blocks):
+                p = f"transformer_blocks.{i}."
+                a = blk.attn
+                if not hasattr(a, "w_kvq") and all(p + f"attn.{n}.{s}" in pend for n in ("to_k", "to_v", "to_q") for s in ("weight", "bias")):
+                    a.w_kvq = torch.cat([take(p + f"attn.{n}.weight") for n in ("to_k", "to_v", "to_q")], 0).contiguous()
+                    a.b_kvq = torch.cat([take(p + f"attn.{n}.bias") for n in ("to_k", "to_v", "to_q")], 0).contiguous()
+                if not hasattr(a, "w_add_kvq") and all(p + f"attn.{n}.{s}" in pend for n in ("add_k_proj", "add_v_proj", "add_q_proj") for s in ("weight", "bias")):
+                    a.w_add_kvq = torch.cat([take(p + f"attn.{n}.weight") for n in ("add_k_proj", "add_v_proj", "add_q_proj")], 0).contiguous()
+                    a.b_add_kvq = torch.cat([take(p + f"attn.{n}.bias") for n in ("add_k_proj", "add_v_proj", "add_q_proj")], 0).contiguous()
+                for src, dst in (("attn.to_out.0.weight", (a, "w_out")), ("attn.to_out.0.bias", (a, "b_out")),
+                                 ("attn.to_add_out.weight", (a, "w_add_out")), ("attn.to_add_out.bias", (a, "b_add_out")),
+                                 ("attn.norm_q.weight", (a, "norm_q")), ("attn.norm_k.weight", (a, "norm_k")),
+                                 ("attn.norm_added_q.weight", (a, "norm_added_q")), ("attn.norm_added_k.weight", (a, "norm_added_k")),
+                                 ("ff.net.0.proj.weight", (blk, "ff_w1")), ("ff.net.0.proj.bias", (blk, "ff_b1")),
+                                 ("ff.net.2.weight", (blk, "ff_w2")), ("ff.net.2.bias", (blk, "ff_b2")),
+                                 ("ff_context.net.0.proj.weight", (blk, "ffc_w1")), ("ff_context.net.0.proj.bias", (blk, "ffc_b1")),
+                                 ("ff_context.net.2.weight", (blk, "ffc_w2")), ("ff_context.net.2.bias", (blk, "ffc_b2"))):
+                    if p + src in pend:
+                        setattr(dst[0], dst[1], take(p + src).contiguous())
+                for src, o in (("norm1.linear", blk.mo_img), ("norm1_context.linear", blk.mo_ctx)):
+                    if p + src + ".weight" in pend:
+                        mod_w[o:o + 6 * d] = take(p + src + ".weight")
+                    if p + src + ".bias" in pend:
+                        mod_b[o:o + 6 * d] = take(p + src + ".bias")
+            for i, blk in enumerate(self.single_transformer_blocks):
+                p = f"single_transformer_blocks.{i}."
+                a = blk.attn
+                names = ("attn.to_k", "attn.to_v", "attn.to_q", "proj_mlp")
+                if not hasattr(a, "w_kvqm") and all(p + f"{n}.{s}" in pend for n in names for s in ("weight", "bias")):
+                    a.w_kvqm = torch.cat([take(p + f"{n}.weight") for n in names], 0).contiguous()
+                    a.b_kvqm = torch.cat([take(p + f"{n}.bias") for n in names], 0).contiguous()
+                for src, dst in (("attn.norm_q.weight", (a, "norm_q")), ("attn.norm_k.weight", (a, "norm_k")),
+                                 ("proj_out.weight", (blk, "w_po")), ("proj_out.bias", (blk, "b_po"))):
+                    if p + src in pend:
+                        setattr(dst[0], dst[1], take(p + src).contiguous())
+                if p + "norm.linear.weight" in pend:
+                    mod_w[blk.mo:blk.mo + 3 * d] = take(p + "norm.linear.weight")
+                if p + "norm.linear.bias" in pend:
+                    mod_b[blk.mo:blk.mo + 3 * d] = take(p + "norm.linear.bias")
+            if "norm_out.linear.weight" in pend:
+                mod_w[self.mo_out:self.mo_out + 2 * d] = take("norm_out.linear.weight")
+            if "norm_out.linear.bias" in pend:
+                mod_b[self.mo_out:self.mo_out + 2 * d] = take("norm_out.linear.bias")
+            for n in ("x_embedder", "context_embedder", "proj_out"):
+                for s in ("weight", "bias"):
+                    if f"{n}.{s}" in pend:
+                        setattr(self, f"{n}_{s}", take(f"{n}.{s}").contiguous())
+            for e in ("timestep_embedder", "guidance_embedder", "text_embedder"):
+                for l in ("linear_1", "linear_2"):
+                    for s in ("weight", "bias"):
+                        k = f"time_text_embed.{e}.{l}.{s}"
+                        if k in pend:
+                            setattr(self, f"tte_{e}_{l}_{s}", take(k).contiguous())
+
+        n = 0
+        for name, t in items:
+            pend[name] = t
+            n += 1
+            if n % 16 == 0:
+                try_finish()
+        try_finish()
+        if pend:
+            raise KeyError(f"unconsumed weights: {sorted(pend)[:5]} ...")
+        return self
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        return self.load_state_dict_stream(sd.items())
+
+    # -- embedders ------------------------------------------------------------------------------------
+    def time_text_embed(self, timestep: torch.Tensor, guidance: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
+        """[EXT] CombinedTimestepGuidanceTextProjEmbeddings; the three MLPs are M=1 GEMVs."""
+        def mlp(e, x):
+            h = ops.gemv(x, getattr(self, f"tte_{e}_linear_1_weight"), getattr(self, f"tte_{e}_linear_1_bias"))
+            return ops.gemv(h, getattr(self, f"tte_{e}_linear_2_weight"), getattr(self, f"tte_{e}_linear_2_bias"),
+                            silu_input=True)
+        te = timestep_embedding(timestep.detach().float().cpu()).to(torch.bfloat16).to(self.device)
+        ge = timestep_embedding(guidance.detach().float().cpu()).to(torch.bfloat16).to(self.device)
+        t, g, p = mlp("timestep_embedder", te), mlp("guidance_embedder", ge), mlp("text_embedder", pooled)
+        return (t + g) + p        # two bf16 adds, same order as the module (tiny [1, d] tensors)
+
+    # -- vanilla forward ------------------------------------------------------------------------------
+    def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
+                img_ids=None, txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True):
+        image_rotary_emb = self.pos_embed(torch.cat((txt_ids.cpu(), img_ids.cpu()), dim=0), self.device)
+        return self._run(hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance,
+                         image_rotary_emb, return_dict)
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict):
+        """Shared body of the vanilla and the RegionE forward (inplace.py:469-576)."""
+        assert hidden_states.shape[0] == 1, "harness engine runs one image per forward"
+        M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
+        R = T + M
+        ws = self.ws
+        ws.ensure(R, R)
+        d = self.cfg_model.d
+        ops.gemm(hidden_states[0], self.x_embedder_weight, self.x_embedder_bias, ws.x[T:R])
+        ops.gemm(encoder_hidden_states[0], self.context_embedder_weight, self.context_embedder_bias, ws.x[:T])
+        ts = timestep.to(torch.bfloat16) * 1000                       # inplace.py:471
+        gd = guidance.to(torch.bfloat16) * 1000
+        temb = self.time_text_embed(ts, gd, pooled)
+        mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
+        ctx = FwdCtx(ws, T, M, mods)
+        for block in self.transformer_blocks:
+            block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
+        for block in self.single_transformer_blocks:
+            block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
+        # norm_out (AdaLayerNormContinuous: scale, shift = chunk(emb, 2)) + proj_out
+        ops.ln_modulate(ws.x[T:R], ws.nrm[T:R], mods.chunk(self.mo_out, 1), mods.chunk(self.mo_out, 0))
+        out = torch.empty(1, M, self.cfg_model.in_channels, dtype=torch.bfloat16, device=self.device)
+        ops.gemm(ws.nrm[T:R], self.proj_out_weight, self.proj_out_bias, out[0])
+        return (out,) if not return_dict else _Cfg(sample=out)
+
+
+# ---------------------------------------------------------------------------------------------
+# [EXT] pipeline (denoise part only: no VAE / text encoders in this harness)
+# ---------------------------------------------------------------------------------------------
+def calculate_shift(image_seq_len, base_seq_len=256, max_seq_len=4096, base_shift=0.5, max_shift=1.15):
+    m = (max_shift - base_shift) / (max_seq_len - base_seq_len)
+    return image_seq_len * m + (base_shift - m * base_seq_len)
+
+
+class FluxPipelineOutput(_Cfg):
+    pass
+
+
+class FluxKontextPipeline:
+    """Vanilla full-token denoise loop.  `image` is the PACKED condition latent [1, L, 64] (the VAE
+    encode of the input image is outside the hot path and outside this harness); prompts are passed
+    as embeddings."""
+
+    vae_scale_factor = 8
+
+    def __init__(self, transformer: FluxTransformer2DModel, scheduler: Optional[FlowMatchEulerDiscreteScheduler] = None):
+        self.transformer = transformer
+        self.scheduler = scheduler or FlowMatchEulerDiscreteScheduler()
+        self._interrupt = False
+
+    @property
+    def interrupt(self):
+        return self._interrupt
+
+    def prepare(self, image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps):
+        dev = self.transformer.device
+        h_tok, w_tok = height // (2 * self.vae_scale_factor), width // (2 * self.vae_scale_factor)
+        L = h_tok * w_tok
+        image_latents = image.to(dev)
+        if latents is None:
+            latents = torch.randn(1, L, self.transformer.cfg_model.in_channels, generator=generator).to(torch.bfloat16)
+        latents = latents.to(dev)
+        ids = torch.zeros(h_tok, w_tok, 3)
+        ids[..., 1] = torch.arange(h_tok)[:, None]
+        ids[..., 2] = torch.arange(w_tok)[None, :]
+        latent_ids = ids.reshape(L, 3)
+        image_ids = latent_ids.clone()
+        image_ids[:, 0] = 1
+        latent_ids = torch.cat([latent_ids, image_ids], dim=0)       # host tensor [2L, 3]
+        text_ids = torch.zeros(prompt_embeds.shape[1], 3)
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        mu = calculate_shift(L, self.scheduler.config.get("base_image_seq_len", 256),
+                             self.scheduler.config.get("max_image_seq_len", 4096),
+                             self.scheduler.config.get("base_shift", 0.5), self.scheduler.config.get("max_shift", 1.15))
+        self.scheduler.set_timesteps(sigmas=sigmas, mu=mu)
+        return latents, image_latents, latent_ids, text_ids, h_tok, w_tok
+
+    @torch.no_grad()
+    def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, height=1024, width=1024,
+                 num_inference_steps=28, guidance_scale=2.5, latents=None, generator=None, output_type="latent",
+                 return_dict=True, callback_on_step_end=None):
+        latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+        timesteps = self.scheduler.timesteps
+        guidance = torch.full([1], guidance_scale, dtype=torch.float32)
+        self.scheduler.set_begin_index(0)
+        for i, t in enumerate(timesteps):
+            x = torch.cat([latents, image_latents], dim=1)
+            timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            noise_pred = self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance,
+                                          pooled_projections=pooled_prompt_embeds,
+                                          encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_ids,
+                                          return_dict=False)[0]
+            noise_pred = noise_pred[:, : latents.size(1)]
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            if callback_on_step_end is not None:
+                callback_on_step_end(self, i, t, {"latents": latents})
+        if not return_dict:
+            return (latents,)
+        return FluxPipelineOutput(images=latents)

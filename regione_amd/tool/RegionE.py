@@ -1,0 +1,61 @@
+"""Plugin facade: same class, method names, kwargs, defaults, asserts and pipeline-class dispatch as
+/root/reference/RegionE/tool/RegionE.py:1-51, on top of the HIP patch sets."""
+import copy
+import importlib
+
+config = {
+    "FluxKontextPipeline": {"num_inference_steps": 28, "warmup_step": 6, "post_step": 2, "refresh_step": "16",
+                            "threshold": 0.93, "cache_threshold": 0.04, "erosion_dilation": True},
+    "Step1XEditPipeline": {"num_inference_steps": 28, "warmup_step": 6, "post_step": 2, "refresh_step": "16",
+                           "threshold": 0.88, "cache_threshold": 0.02, "erosion_dilation": True},
+    "Step1XEditPipelineV1P2": {"num_inference_steps": 28, "warmup_step": 6, "post_step": 2, "refresh_step": "16",
+                               "threshold": 0.88, "cache_threshold": 0.02, "erosion_dilation": True},
+    "QwenImageEditPipeline": {"num_inference_steps": 28, "warmup_step": 6, "post_step": 2, "refresh_step": "16",
+                              "threshold": 0.80, "cache_threshold": 0.03, "erosion_dilation": True},
+    "QwenImageEditPlusPipeline": {"num_inference_steps": 28, "warmup_step": 6, "post_step": 2, "refresh_step": "16",
+                                  "threshold": 0.80, "cache_threshold": 0.03, "erosion_dilation": True},
+}
+
+# pipeline class name -> patch-set module (RegionE/tool/RegionE.py:15-41 dispatch)
+_FAMILY = {
+    "FluxKontextPipeline": "FluxKontext",
+    "Step1XEditPipeline": "Step1XEdit",
+    "Step1XEditPipelineV1P2": "Step1XEditV1P2",
+    "QwenImageEditPipeline": "QwenImageEdit",
+    "QwenImageEditPlusPipeline": "QwenImageEditPlus",
+}
+
+
+class RegionEHelper(object):
+    def __init__(self, pipeline=None):
+        if pipeline is not None:
+            self.pipeline = pipeline
+        self.name = self.pipeline.__class__.__name__
+        # per-helper copy: the reference mutates the module-level dict in set_params (RegionE.py:43-51),
+        # which leaks settings between helpers; same defaults, no leak.
+        self.config = copy.deepcopy(config[self.name])
+
+    def _family(self):
+        try:
+            return importlib.import_module(f"regione_amd.{_FAMILY[self.name]}.inplace")
+        except ModuleNotFoundError as e:
+            raise NotImplementedError(f"RegionE patch set for {self.name} is not built yet") from e
+
+    def enable(self):
+        assert self.pipeline is not None
+        self.pipeline = self._family().warp_modules(self.pipeline, **self.config)
+
+    def disable(self):
+        assert self.pipeline is not None
+        self.pipeline = self._family().unwarp_modules(self.pipeline)
+
+    def set_params(self, num_inference_steps=28, warmup_step=None, post_step=None, refresh_step=None, threshold=None,
+                   cache_threshold=None, erosion_dilation=None):
+        assert num_inference_steps == 28, "num_inference_steps must be 28"
+        if warmup_step is not None: self.config['warmup_step'] = warmup_step
+        if post_step is not None: self.config['post_step'] = post_step
+        if refresh_step is not None: self.config['refresh_step'] = refresh_step
+        if threshold is not None: self.config['threshold'] = threshold
+        if cache_threshold is not None: self.config['cache_threshold'] = cache_threshold
+        if erosion_dilation is not None: self.config['erosion_dilation'] = erosion_dilation
+        print(f"RegionEHelper: set_params {self.config}")

