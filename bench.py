@@ -1,0 +1,350 @@
+#!/usr/bin/env python3
+"""bench.py - denoising steps/s of the RegionE hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" of this contract = one complete 28-step RegionE edit (one pass of the hot path over one
+image): the F/R/C kind of a denoising step depends on its index, so the edit is the smallest unit
+whose cost is well defined.  `value` = denoising steps per second = 28 * K * N / T (whole job, all
+ranks, max-over-ranks time), `ms_per_step` = wall-clock per edit (the "end-to-end edit wall-clock"
+half of the metric; encoders / VAE are outside the hot path).
+
+Workload (BASELINE.json configs[1]): FLUX.1-Kontext-dev dims (19 double + 38 single blocks,
+d = 3072, 24 x 128 heads, d_ff = 12288; 11.9 B parameters), 1024 x 1024 -> L = L_c = 4096 tokens,
+T = 512 text tokens, 28 steps, warmup 6 / post 2 / refresh "16", threshold 0.88, bf16.  Weights
+N(0, 0.02^2) and latents N(0,1) are synthetic (no network for checkpoints); the edited region is
+forced to 25 % of the tokens by construction by substituting, at step
+warmup-1 only, a velocity whose one-step estimate is `condition + 0.1 N(0,1)` outside a rectangle -
+the transformer still runs on that step, nothing is skipped.
+
+Multi-GPU: one process per GPU, one image per rank (the path shards per image; SURVEY.md section
+8e), weights replicated, no collective on the data path; the final latents are all-gathered to
+every rank over RCCL inside the timed region (512 KB per image).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+N_STEPS = 28
+
+
+def algorithmic_flops(cfg, T, N, K_e):
+    """G = 8 d^2 + 4 d d_ff per token per block."""
+    d, ff, nl = cfg.d, cfg.d * cfg.mlp_ratio, cfg.n_layers
+    G = 8 * d * d + 4 * d * ff
+    S = T + N
+    f_full = nl * (S * G + 4 * S * S * d)
+    f_reg = nl * (T + K_e) * (G + 4 * S * d)
+    return f_full, f_reg
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def wrap(self, ops_mod):
+        import regione_amd.ops as ops
+        self._orig_gemm, self._orig_attn = ops.gemm, ops.attention
+        timer = self
+
+        def gemm(A, W, bias, out, **kw):
+            M, K = A.shape
+            N = W.shape[0]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig_gemm(A, W, bias, out, **kw)
+            e.record()
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * M * N * K))
+            return r
+
+        def attention(q, k_slab, vt_slab, out, skv, H, scale=None):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig_attn(q, k_slab, vt_slab, out, skv, H, scale)
+            e.record()
+            timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * H * 128))
+            return r
+
+        ops.gemm, ops.attention = gemm, attention
+
+    def unwrap(self):
+        import regione_amd.ops as ops
+        ops.gemm, ops.attention = self._orig_gemm, self._orig_attn
+
+    def summary(self):
+        out = {}
+        for name, lst in self.rec.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+            fl = sum(f for _, _, f in lst)
+            out[name] = dict(launches=len(lst), total_ms=ms, avg_us=1e3 * ms / len(lst), flops_per_launch=fl / len(lst),
+                             achieved_tflops=fl / (ms * 1e-3) / 1e12)
+        return out
+
+
+def build_pipeline(cfg, device, seed):
+    from regione_amd import synth
+    from regione_amd.harness import flux as H
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def gen():
+        for name, shape in synth.flux_param_shapes(cfg).items():
+            if name.endswith(".bias"):
+                t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.01
+            elif len(shape) == 1:
+                t = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+            else:
+                t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.02
+            yield name, t.to(torch.bfloat16)
+    tr = H.FluxTransformer2DModel(cfg, device).load_state_dict_stream(gen())
+    return H.FluxKontextPipeline(tr)
+
+
+def install_region_injection(pipe, h_tok, w_tok, box, image_latents, seed):
+    """At step warmup-1 replace the model output by a velocity whose one-step estimate is the target
+    (condition + 0.1 noise outside `box`, fresh noise inside): fixes K_e by construction."""
+    from regione_amd import synth
+    tgt = synth.region_target(h_tok, w_tok, box, image_latents.cpu(), seed=seed, ramp=0.0)
+    g = torch.Generator().manual_seed(seed + 1)
+    tgt = tgt + 0.1 * torch.randn(tgt.shape, generator=g)
+    r0, r1, c0, c1 = box
+    tgt = tgt.to(image_latents.device)
+    sch = pipe.scheduler
+    orig = sch.step
+    M = pipe._regione_manager
+
+    def step(model_output, timestep, sample, **kw):
+        if M.current_step == M.warmup_step - 1:
+            i = sch._step_index if sch._step_index is not None else M.current_step
+            dt_final = float(sch.sigmas[-1] - sch.sigmas[i])
+            model_output = ((tgt[None] - sample.float()) / dt_final).to(model_output.dtype)
+        return orig(model_output, timestep, sample, **kw)
+    sch.step = step
+
+
+def cpu_baseline(cfg, T, N, K_e, plan):
+    """Oracle ('port') timed on the host cores on a bounded sample: ONE double and ONE single block
+    (fp32, torch-CPU eager, all cores) at FULL (T+N rows) and REGION (T+K_e query rows) length,
+    extrapolated x layer counts x the F/R/C plan to steps/s."""
+    from oracle import regione_oracle as O
+    from regione_amd import synth
+    torch.set_num_threads(os.cpu_count())
+    one = synth.FluxConfig(in_channels=cfg.in_channels, n_double=1, n_single=1, heads=cfg.heads, head_dim=cfg.head_dim,
+                           joint_dim=cfg.joint_dim, pooled_dim=cfg.pooled_dim)
+    w = synth.make_flux_weights(one, seed=1, dtype=torch.float32)
+    d = cfg.d
+    g = torch.Generator().manual_seed(0)
+    L = N // 2
+    h_tok = int(round(L ** 0.5))
+    ids = torch.cat([torch.zeros(T, 3), synth.flux_latent_ids(h_tok, L // h_tok)], 0)
+    rope_full = O.flux_pos_embed(ids)
+    st = O.RegionState()
+    st.set_parameters(28, 6, 2, "16", 0.88, 0.04, True)
+    st.refresh(None, None, T, h_tok, L // h_tok)
+    temb = torch.randn(1, d, generator=g)
+    caches = [O.KVCache(), O.KVCache()]
+    times = {}
+    with torch.no_grad():
+        # FULL + store
+        st.current_step = st.warmup_step - 1
+        h, c = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g)
+        t0 = time.perf_counter()
+        c2, h2 = O.double_block(w, "transformer_blocks.0", cfg.heads, st, caches[0], h, c, temb, rope_full, rope_full)
+        times["double_full"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h2, c2, temb, rope_full, rope_full)
+        times["single_full"] = time.perf_counter() - t0
+        # REGION (update phase)
+        st.current_step = st.warmup_step
+        st.edited_ids = torch.arange(K_e).unsqueeze(0)
+        sel = torch.cat([torch.arange(T), T + st.edited_ids[0]])
+        rope_q = (rope_full[0][sel], rope_full[1][sel])
+        h, c = torch.randn(1, K_e, d, generator=g), torch.randn(1, T, d, generator=g)
+        t0 = time.perf_counter()
+        c2, h2 = O.double_block(w, "transformer_blocks.0", cfg.heads, st, caches[0], h, c, temb, rope_q, rope_full)
+        times["double_region"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h2, c2, temb, rope_q, rope_full)
+        times["single_region"] = time.perf_counter() - t0
+    n_full = sum(1 for p in plan if p in "FS")
+    n_reg = plan.count("R")
+    edit_s = n_full * (cfg.n_double * times["double_full"] + cfg.n_single * times["single_full"]) + \
+        n_reg * (cfg.n_double * times["double_region"] + cfg.n_single * times["single_region"])
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=N_STEPS / edit_s, unit="steps/s", cores=os.cpu_count(), kind="port",
+                sample=(f"oracle (torch-CPU eager fp32, {os.cpu_count()} threads, {cpu_model}): 1 double + 1 single block at "
+                        f"FULL ({T}+{N} rows) and REGION ({T}+{K_e} query rows) timed once = {sum(times.values()):.1f} s of CPU "
+                        f"work, extrapolated x{cfg.n_double}/{cfg.n_single} layers x plan {n_full}F/{n_reg}R/"
+                        f"{plan.count('C')}C -> {edit_s:.0f} s per edit"),
+                block_seconds=times)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed edits (28 denoising steps each)")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up edits")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--edit-frac", type=float, default=0.25)
+    ap.add_argument("--toy", action="store_true", help="toy model (debugging only; result is not a valid bench line)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vanilla", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=device)
+
+    from regione_amd import RegionEHelper, synth, ops
+    from oracle import regione_oracle as O            # checker / cpu_baseline leg only
+
+    cfg = synth.FluxConfig(**synth.TOY) if args.toy else synth.FluxConfig()
+    T = 32 if args.toy else 512
+    h_tok = w_tok = args.size // 16
+    L = h_tok * w_tok
+    N = 2 * L
+    side = int(round((args.edit_frac * L) ** 0.5))
+    box_side = max(side - 2, 3)                      # erosion -1 ring, dilation +2 rings -> side x side
+    r0 = (h_tok - box_side) // 2
+    box = (r0, r0 + box_side, r0, r0 + box_side)
+
+    t_build = time.perf_counter()
+    pipe = build_pipeline(cfg, device, seed=42)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    lat, img, prompt, pooled = synth.make_edit_inputs(h_tok, w_tok, T, cfg, seed=110 + rank, dtype=torch.bfloat16)
+    lat, img, prompt, pooled = lat.to(device), img.to(device), prompt.to(device), pooled.to(device)
+
+    helper = RegionEHelper(pipe)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # stdout carries exactly one JSON line
+        helper.set_params(threshold=0.88, cache_threshold=0.04, warmup_step=6, post_step=2, refresh_step="16")
+    helper.enable()
+    install_region_injection(pipe, h_tok, w_tok, box, img[0:1], seed=7)
+
+    def edit(trace=None):
+        return pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=args.size, width=args.size,
+                    latents=lat, guidance_scale=2.5, return_dict=False, trace=trace)[0]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = edit()
+    timer = KernelTimer()
+    timer.wrap(ops)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = edit()
+        if dist is not None:
+            gathered = [torch.empty_like(out) for _ in range(world)]
+            dist.all_gather(gathered, out)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    timer.unwrap()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # characterise the run (untimed): step kinds, K_e
+    trace = {}
+    out = edit(trace)
+    torch.cuda.synchronize()
+    kinds = "".join(trace["kind"])
+    K_e = int(pipe._regione_manager.edited_ids.shape[1])
+    f_full, f_reg = algorithmic_flops(cfg, T, N, K_e)
+    n_full, n_reg, n_cache = kinds.count("F"), kinds.count("R"), kinds.count("C")
+    flops_edit = n_full * f_full + n_reg * f_reg
+    edit_s = elapsed / args.steps
+    ksum = timer.summary()
+
+    result = {
+        "metric": "denoising steps/sec (28-step RegionE edit, 1024x1024)", "value": N_STEPS * args.steps * world / elapsed,
+        "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * edit_s,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"FLUX.1-Kontext-dev {args.size}x{args.size} 28-step RegionE edit, warmup=6 post=2 refresh=16 "
+                               f"thresh=0.88 cache_thresh=0.04, L=L_c={L}, T={T}, K_e={K_e} ({100.0 * K_e / L:.1f}% edited by "
+                               f"construction), plan {kinds}", "images_per_gpu": 1, "parallelism": f"image-sharded x{world}",
+                   "params_billion": round(sum(int(torch.tensor(s).prod()) for s in synth.flux_param_shapes(cfg).values()) / 1e9, 2)},
+        "edit_wall_clock_s": edit_s,
+        "algorithmic_tflop_per_edit": flops_edit / 1e12,
+        "loop_mfma_frac": flops_edit / edit_s / 1e12 / PEAK_BF16_TFLOPS,
+        "model_build_s": t_build,
+    }
+    if "gemm_bf16_kernel" in ksum:
+        k = ksum["gemm_bf16_kernel"]
+        result["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": k["achieved_tflops"],
+                              "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
+                              "traffic": None, "launches": k["launches"], "avg_launch_us": k["avg_us"],
+                              "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
+    if "attention_kernel" in ksum:
+        k = ksum["attention_kernel"]
+        result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_kernel", "achieved": k["achieved_tflops"],
+                                        "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
+                                        "launches": k["launches"], "avg_launch_us": k["avg_us"],
+                                        "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
+
+    if rank == 0 and world == 1 and not args.no_vanilla:
+        # full-token denoising on the same engine: the speed-up the reference headlines (README.md:23)
+        helper.disable()
+        van = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=args.size, width=args.size,
+                   latents=lat, guidance_scale=2.5, return_dict=False)[0]       # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        van = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=args.size, width=args.size,
+                   latents=lat, guidance_scale=2.5, return_dict=False)[0]
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - t0
+        result["full_token"] = {"edit_wall_clock_s": tv, "steps_per_s": N_STEPS / tv,
+                                "mfma_frac": N_STEPS * f_full / tv / 1e12 / PEAK_BF16_TFLOPS}
+        result["speedup_vs_full_token"] = tv / edit_s
+        result["psnr_vs_full_token_db"] = O.psnr(out.cpu(), van.cpu())
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        plan = "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04))
+        result["cpu_baseline"] = cpu_baseline(cfg, T, N, K_e, plan)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,11 +80,14 @@ int rgn_euler_step(const void* sample, int sample_dtype, const void* v, int v_dt
 
 /* ------------------------------------------------------------------------------------------
  * a6  Adaptive Velocity Decay cache hit (inplace.py:315-318):
- *   out[k,:] = round_c( round_c(ratio) * cache[ids ? ids[k] : k, :] )
+ *   out[k,:] = round_c( r * cache[ids ? ids[k] : k, :] ),   r = round_ratio ? round_c(ratio) : ratio
  * The optional ids fuse the first-hit gather (inplace.py:316-317).
+ * `cache * ratio` multiplies a bf16 tensor by a 0-dim fp32 tensor.  Torch's CPU kernel keeps the
+ * scalar in fp32 (round_ratio = 0, what the reference-generated fixtures contain); its CUDA kernel
+ * casts a *device* 0-dim tensor to bf16 first (round_ratio = 1).  Both are offered.
  */
-int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio, void* out, int K, int D,
-                  void* stream);
+int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio, int round_ratio, void* out,
+                  int K, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM  C = epilogue(A[M,K] @ W[N,K]^T + bias)  (fp32 accumulate).

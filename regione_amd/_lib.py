@@ -25,7 +25,7 @@ SIGNATURES = {
     "rgn_scatter_rows": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
     "rgn_euler_step": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_float, _c_float, _c_int,
                        _c_int, _c_void_p],
-    "rgn_avd_apply": [_c_void_p, _c_int, _c_void_p, _c_float, _c_void_p, _c_int, _c_int, _c_void_p],
+    "rgn_avd_apply": [_c_void_p, _c_int, _c_void_p, _c_float, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
     "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                       _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "rgn_gemv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,

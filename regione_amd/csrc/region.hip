@@ -183,14 +183,14 @@ __global__ void euler_kernel(const TS* __restrict__ sample, const TV* __restrict
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void avd_kernel(const T* __restrict__ cache, const int64_t* __restrict__ ids, float ratio,
-                           T* __restrict__ out, size_t n, int D) {
+                           int round_ratio, T* __restrict__ out, size_t n, int D) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         size_t src = i;
         if (ids != nullptr) {
             size_t k = i / D;
             src = (size_t)ids[k] * D + (i - k * D);
         }
-        if constexpr (sizeof(T) == 2) out[i] = f2bf(__fmul_rn(rbf(ratio), bf2f(cache[src])));
+        if constexpr (sizeof(T) == 2) out[i] = f2bf(__fmul_rn(round_ratio ? rbf(ratio) : ratio, bf2f(cache[src])));
         else out[i] = __fmul_rn(ratio, cache[src]);
     }
 }
@@ -317,14 +317,15 @@ int rgn_euler_step(const void* sample, int sample_dtype, const void* v, int v_dt
     return check_launch("euler_kernel");
 }
 
-int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio, void* out, int K, int D, void* stream) {
+int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio, int round_ratio, void* out, int K,
+                  int D, void* stream) {
     if (K == 0) return 0;
     if (!cache || !out || K < 0 || D <= 0) return fail(RGN_E_BADARG, "avd: bad argument");
     hipStream_t st = (hipStream_t)stream;
     size_t n = (size_t)K * D;
     int g = grid_for(n, 256);
-    if (dtype == RGN_BF16) hipLaunchKernelGGL((avd_kernel<uint16_t>), dim3(g), dim3(256), 0, st, (const uint16_t*)cache, ids, ratio, (uint16_t*)out, n, D);
-    else hipLaunchKernelGGL((avd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)cache, ids, ratio, (float*)out, n, D);
+    if (dtype == RGN_BF16) hipLaunchKernelGGL((avd_kernel<uint16_t>), dim3(g), dim3(256), 0, st, (const uint16_t*)cache, ids, ratio, round_ratio, (uint16_t*)out, n, D);
+    else hipLaunchKernelGGL((avd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)cache, ids, ratio, round_ratio, (float*)out, n, D);
     return check_launch("avd_kernel");
 }
 

@@ -122,12 +122,14 @@ def euler_step(sample: torch.Tensor, v: torch.Tensor, dt: float, mask: Optional[
     return out.unsqueeze(0) if v.dim() == 3 else out
 
 
-def avd_apply(cache: torch.Tensor, ratio: float, ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+def avd_apply(cache: torch.Tensor, ratio: float, ids: Optional[torch.Tensor] = None,
+              round_ratio: bool = False) -> torch.Tensor:
     c = _rows(cache)
     idv = ids.reshape(-1).contiguous() if ids is not None else None
     K = idv.numel() if idv is not None else c.shape[0]
     out = torch.empty((K, c.shape[1]), dtype=c.dtype, device=c.device)
-    rc = _lib.lib().rgn_avd_apply(_p(c), _dt(c), _p(idv), float(ratio), _p(out), K, c.shape[1], _stream())
+    rc = _lib.lib().rgn_avd_apply(_p(c), _dt(c), _p(idv), float(ratio), int(round_ratio), _p(out), K, c.shape[1],
+                                  _stream())
     _lib.check(rc, "rgn_avd_apply")
     return out.unsqueeze(0) if cache.dim() == 3 else out
 

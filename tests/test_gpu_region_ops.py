@@ -117,9 +117,12 @@ def test_avd_apply_bit_exact(dtype):
     from regione_amd import ops
     gen = torch.Generator().manual_seed(2)
     c = torch.randn(1, 4096, 64, generator=gen).to(dtype)
-    ratio = torch.tensor(0.9876543, dtype=torch.float16) * torch.tensor(1.0 + 0.0123)      # fp16*fp32 -> fp32
+    ratio = torch.tensor(0.9876543, dtype=torch.float16) * torch.tensor(1.0 - 0.0123)      # fp16*fp32 -> fp32
     ref = c * ratio                                                                         # inplace.py:318
     assert torch.equal(ops.avd_apply(c.cuda(), float(ratio)).cpu(), ref)
+    # CUDA-eager flavour: a device 0-dim ratio is cast to the cache dtype first
+    ref_dev = (c.float() * ratio.to(dtype).float()).to(dtype)
+    assert torch.equal(ops.avd_apply(c.cuda(), float(ratio), round_ratio=True).cpu(), ref_dev)
     ids = torch.randperm(4096, generator=gen)[:777].sort().values.unsqueeze(0)
     ref2 = O.ids_gather(c, ids) * ratio                                                     # :316-318
     assert torch.equal(ops.avd_apply(c.cuda(), float(ratio), ids.cuda()).cpu(), ref2)
