@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch ships its own libamdhip64; it must be in the process BEFORE libregione_hip.so is dlopen'ed so
+# that both resolve to the same HIP runtime (loading ours first binds /opt/rocm's copy and the two
+# runtimes then disagree about the device: "no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 from .build import LIB_PATH
 
 _c_void_p, _c_int, _c_float = C.c_void_p, C.c_int, C.c_float
