@@ -58,8 +58,17 @@ class KernelTimer:
 
     def wrap(self, ops_mod):
         import regione_amd.ops as ops
-        self._orig_gemm, self._orig_attn = ops.gemm, ops.attention
+        self._orig_gemm, self._orig_attn, self._orig_pair = ops.gemm, ops.attention, ops.gemm_pair
         timer = self
+
+        def gemm_pair(A0, W0, b0, o0, A1, W1, b1, o1, **kw):
+            N, K = W0.shape
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig_pair(A0, W0, b0, o0, A1, W1, b1, o1, **kw)
+            e.record()
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (A0.shape[0] + A1.shape[0]) * N * K))
+            return r
 
         def gemm(A, W, bias, out, **kw):
             M, K = A.shape
@@ -79,11 +88,11 @@ class KernelTimer:
             timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * H * 128))
             return r
 
-        ops.gemm, ops.attention = gemm, attention
+        ops.gemm, ops.attention, ops.gemm_pair = gemm, attention, gemm_pair
 
     def unwrap(self):
         import regione_amd.ops as ops
-        ops.gemm, ops.attention = self._orig_gemm, self._orig_attn
+        ops.gemm, ops.attention, ops.gemm_pair = self._orig_gemm, self._orig_attn, self._orig_pair
 
     def summary(self):
         out = {}

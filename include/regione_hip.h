@@ -106,6 +106,14 @@ int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bi
                   int M, int N, int K, int epilogue, int gelu_from_col, const void* gate,
                   const void* resid, const int64_t* out_rows, void* stream);
 
+/* Two independent problems with the same N, K and epilogue in ONE launch (the text and image
+ * streams of a double block: different A / W / bias / C / gate / resid).  The small problem's tiles
+ * fill the tail of the large one instead of running as an under-occupied launch of their own. */
+int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
+                       const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1,
+                       const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1,
+                       int N, int K, int epilogue, int gelu_from_col, void* stream);
+
 /* Skinny GEMV for the AdaLN modulation / timestep embedders:
  *   y[b,n] = bf16( sum_k W[n,k] * act(x[b,k]) + bias[n] ),  act = silu (rounded to bf16) if silu_input.
  * B <= 4, K % 8 == 0.  HBM-bound on W. */

@@ -33,6 +33,9 @@ SIGNATURES = {
     "rgn_avd_apply": [_c_void_p, _c_int, _c_void_p, _c_float, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
     "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                       _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "rgn_gemm_bf16_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
+                           _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
+                           _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "rgn_gemv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_void_p],
     "rgn_ln_modulate": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p,

@@ -18,6 +18,7 @@
 // GEMM `_partially_linear` (RegionE/FluxKontext/fused_kernels.py:9-101).  Unlike the Triton kernel
 // the result is rounded ONCE to the cache dtype (no fp16 round trip, quirk A-3).
 #include "common.h"
+#include <stdlib.h>
 
 namespace rgn {
 
@@ -38,33 +39,50 @@ struct GemmArgs {
     int gelu_from_col;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
-constexpr int CT_LD = BN + 8;                    // padded bf16 row of the C staging tile
+constexpr int BK = 64;
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // torch GELU(approximate='tanh') opmath: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
-    const float kBeta = 0.7978845608028654f * 1.0f, kKappa = 0.044715f;
+    const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
     float inner = kBeta * (x + kKappa * x * x * x);
     return 0.5f * x * (1.0f + tanhf(inner));
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+struct GemmGroup {
+    GemmArgs p[2];      // up to two problems per launch (e.g. text + image stream of a double block)
+    int nt0;            // tiles of problem 0; tiles >= nt0 belong to problem 1
+    int nt;             // total tiles
+};
 
-    // ---- XCD-aware bijective tile map (T1) + grouped ordering --------------------------------
-    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN, nt = ntm * ntn;
+// Tile configurations:
+//   <128,128,2,2>: 4 waves, wave tile 64x64, 64 KiB LDS, 2 blocks/CU  - small / ragged problems
+//   <256,256,2,4>: 8 waves, wave tile 128x64, 128 KiB LDS, 1 block/CU - large problems (half the
+//                  global->LDS traffic and 25 % less LDS read traffic per FLOP)
+template <int EPI, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf16_kernel(const GemmGroup gg) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16x16 MFMA tiles per wave
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB DMA pieces per wave per stage
+    constexpr int CT_LD = BN + 8;                              // padded bf16 row of the C staging tile
+    constexpr int CROWS = BM / WM;                             // C rows staged per epilogue chunk
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- XCD-aware bijective tile map (T1) over both problems + grouped ordering ------------------
     int t;
     {
         const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-        const int q = nt >> 3, r = nt & 7;
+        const int q = gg.nt >> 3, r = gg.nt & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    constexpr int GROUP_M = 8;
+    const int pi = (t >= gg.nt0) ? 1 : 0;
+    const GemmArgs& g = gg.p[pi];
+    t -= pi ? gg.nt0 : 0;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    constexpr int GROUP_M = (BM >= 256) ? 4 : 8;
     const int per_group = GROUP_M * ntn;
     const int group = t / per_group, first_m = group * GROUP_M;
     const int gsize = min(ntm - first_m, GROUP_M);
@@ -72,44 +90,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
     const int tn = (t % per_group) / gsize;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // ---- staging addresses: 4 A + 4 B DMA pieces per wave per stage --------------------------
+    // ---- staging addresses ---------------------------------------------------------------------
     const int srow = lane >> 3;                    // row inside an 8-row piece
     const int schunk = (lane & 7) ^ srow;          // source 16-B chunk for LDS slot (lane&7)
-    const uint8_t* a_src[4];
-    const uint8_t* b_src[4];
+    const uint8_t* a_src[PA];
+    const uint8_t* b_src[PB];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = (wave * 4 + q) * 8 + srow;
-        const int ar = min(m0 + row, g.M - 1), br = min(n0 + row, g.N - 1);
+    for (int q = 0; q < PA; ++q) {
+        const int ar = min(m0 + (wave * PA + q) * 8 + srow, g.M - 1);
         a_src[q] = (const uint8_t*)(g.A + (size_t)ar * g.lda) + schunk * 16;
+    }
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+        const int br = min(n0 + (wave * PB + q) * 8 + srow, g.N - 1);
         b_src[q] = (const uint8_t*)(g.W + (size_t)br * g.ldw) + schunk * 16;
     }
     auto stage = [&](int kt, int buf) {
-        uint8_t* base = smem + buf * STAGE_BYTES + (wave * 4) * 1024;
+        uint8_t* base = smem + buf * STAGE;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PA; ++q)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[q] + (size_t)kt * (BK * 2)),
-                                             (lds_ptr_t)(base + q * 1024), 16, 0, 0);
+                                             (lds_ptr_t)(base + (wave * PA + q) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int q = 0; q < PB; ++q)
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(b_src[q] + (size_t)kt * (BK * 2)),
-                                             (lds_ptr_t)(base + TILE_BYTES + q * 1024), 16, 0, 0);
-        }
+                                             (lds_ptr_t)(base + A_BYTES + (wave * PB + q) * 1024), 16, 0, 0);
     };
 
-    // ---- fragment read offsets (swizzled) -----------------------------------------------------
+    // ---- fragment read offsets (swizzled) -------------------------------------------------------
     const int frow = lane & 15, fk = lane >> 4;
     int a_off[2], b_off[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int slot = (kk * 4 + fk) ^ (frow & 7);
-        a_off[kk] = (wm * 64 + frow) * 128 + slot * 16;
-        b_off[kk] = TILE_BYTES + (wn * 64 + frow) * 128 + slot * 16;
+        a_off[kk] = (wm * (BM / WM) + frow) * 128 + slot * 16;
+        b_off[kk] = A_BYTES + (wn * (BN / WN) + frow) * 128 + slot * 16;
     }
 
-    f32x4 acc[4][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = g.K / BK;
     stage(0, 0);
@@ -118,42 +140,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const uint8_t* sb = smem + cur * STAGE_BYTES;
+        const uint8_t* sb = smem + cur * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf8_t af[4], bfr[4];
+            bf8_t af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *(const bf8_t*)(sb + a_off[kk] + i * 2048);
+            for (int j = 0; j < TN; ++j) bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
+            for (int i = 0; i < TM; ++i) af[i] = *(const bf8_t*)(sb + a_off[kk] + i * 2048);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // ---- epilogue: acc + bias -> bf16 -> LDS C tile -------------------------------------------
-    uint16_t* ct = (uint16_t*)smem;                 // 128 x CT_LD bf16 = 34 KiB (stages are free now)
-    {
-        const int ccol = lane & 15, crow = (lane >> 4) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + ccol;
-            const float bv = (g.bias != nullptr && n < g.N) ? bf2f(g.bias[n]) : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    ct[(wm * 64 + i * 16 + crow + r) * CT_LD + wn * 64 + j * 16 + ccol] = f2bf(acc[i][j][r] + bv);
-        }
-    }
-    __syncthreads();
-    // ---- 16-byte row-contiguous stores with the fused epilogue --------------------------------
-    const int vc = tid & 15;                         // 8-column vector inside the tile row
+    // ---- epilogue: per row-chunk (one wave row): acc + bias -> bf16 -> LDS -> 16-byte stores ------
+    uint16_t* ct = (uint16_t*)smem;                 // CROWS x CT_LD bf16 (stages are free now)
+    constexpr int VPR = BN / 8;                     // 8-column vectors per tile row
+    constexpr int RPP = NT / VPR;                   // rows per store pass
+    const int vc = tid % VPR;
     const int ncol = n0 + vc * 8;
     const bool full_vec = (ncol + 8 <= g.N);
     uint16_t gv[8];
@@ -162,34 +171,52 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmArgs g) {
         for (int e = 0; e < 8; ++e) gv[e] = (ncol + e < g.N) ? g.gate[ncol + e] : 0;
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = (tid >> 4) + it * 16;
-        const int m = m0 + row;
-        if (m >= g.M || ncol >= g.N) continue;
-        const size_t orow = g.out_rows ? (size_t)g.out_rows[m] : (size_t)m;
-        uint16_t v[8];
-        *(uint4*)v = *(const uint4*)(ct + row * CT_LD + vc * 8);
-        uint16_t* dst = g.C + orow * g.ldc + ncol;
-        if (EPI == RGN_EPI_GELU) {
+    for (int ch = 0; ch < WM; ++ch) {
+        if (wm == ch) {
+            const int ccol = lane & 15, crow = (lane >> 4) * 4;
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));
-        } else if (EPI == RGN_EPI_GATE_RESID) {
-            const uint16_t* rs = g.resid + orow * g.ldc + ncol;
-            uint16_t rv[8];
-            if (full_vec) *(uint4*)rv = *(const uint4*)rs;
-            else
-                for (int e = 0; e < 8; ++e) rv[e] = (ncol + e < g.N) ? rs[e] : 0;
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / WN) + j * 16 + ccol;
+                const float bv = (g.bias != nullptr && n < g.N) ? bf2f(g.bias[n]) : 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float gated = rbf(bf2f(gv[e]) * bf2f(v[e]));      // gate.unsqueeze(1) * out (bf16)
-                v[e] = f2bf(bf2f(rv[e]) + gated);                         // residual + ... (bf16)
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ct[(i * 16 + crow + r) * CT_LD + wn * (BN / WN) + j * 16 + ccol] = f2bf(acc[i][j][r] + bv);
             }
         }
-        if (full_vec) *(uint4*)dst = *(const uint4*)v;
-        else
-            for (int e = 0; e < 8; ++e)
-                if (ncol + e < g.N) dst[e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < CROWS / RPP; ++it) {
+            const int row = tid / VPR + it * RPP;
+            const int m = m0 + ch * CROWS + row;
+            if (m >= g.M || ncol >= g.N) continue;
+            const size_t orow = g.out_rows ? (size_t)g.out_rows[m] : (size_t)m;
+            uint16_t v[8];
+            *(uint4*)v = *(const uint4*)(ct + row * CT_LD + vc * 8);
+            uint16_t* dst = g.C + orow * g.ldc + ncol;
+            if (EPI == RGN_EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));
+            } else if (EPI == RGN_EPI_GATE_RESID) {
+                const uint16_t* rs = g.resid + orow * g.ldc + ncol;
+                uint16_t rv[8];
+                if (full_vec) *(uint4*)rv = *(const uint4*)rs;
+                else
+                    for (int e = 0; e < 8; ++e) rv[e] = (ncol + e < g.N) ? rs[e] : 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float gated = rbf(bf2f(gv[e]) * bf2f(v[e]));      // gate.unsqueeze(1) * out (bf16)
+                    v[e] = f2bf(bf2f(rv[e]) + gated);                         // residual + ... (bf16)
+                }
+            }
+            if (full_vec) *(uint4*)dst = *(const uint4*)v;
+            else
+                for (int e = 0; e < 8; ++e)
+                    if (ncol + e < g.N) dst[e] = v[e];
+        }
+        if (ch + 1 < WM) __syncthreads();
     }
 }
 
@@ -235,39 +262,93 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const uint16_t* __restri
 
 using namespace rgn;
 
-extern "C" {
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
+    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    constexpr int NT = 64 * WM * WN;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+    }
+    switch (epilogue) {
+        case RGN_EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN>), dim3(gg.nt), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_GELU: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN>), dim3(gg.nt), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN>), dim3(gg.nt), dim3(NT), LDS, st, gg); break;
+        default: return fail(RGN_E_BADARG, "gemm: unknown epilogue");
+    }
+    return check_launch("gemm_bf16_kernel");
+}
 
-int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
-                  int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
-                  const int64_t* out_rows, void* stream) {
-    if (M == 0) return 0;
+static int check_problem(const void* A, int lda, const void* W, int ldw, const void* C, int ldc, int M, int N, int K,
+                         int epilogue, const void* gate, const void* resid) {
     if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return fail(RGN_E_BADARG, "gemm: bad argument");
     if (K % BK != 0) return fail(RGN_E_UNSUPPORTED, "gemm: K must be a multiple of 64");
     if ((lda % 8) || (ldw % 8) || (ldc % 8)) return fail(RGN_E_UNSUPPORTED, "gemm: row strides must be multiples of 8");
     if ((((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)resid) & 15) != 0)
         return fail(RGN_E_UNSUPPORTED, "gemm: pointers must be 16-byte aligned");
     if (epilogue == RGN_EPI_GATE_RESID && (!gate || !resid)) return fail(RGN_E_BADARG, "gemm: gate/resid missing");
-    GemmArgs g;
+    return 0;
+}
+
+static inline int tiles(int M, int N, int b) { return ((M + b - 1) / b) * ((N + b - 1) / b); }
+
+static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, hipStream_t st) {
+    // tile choice by estimated throughput = asymptotic rate x wave-quantisation efficiency:
+    // 256x256 (1 block/CU, 256 slots, ~1150 TF) vs 128x128 (2 blocks/CU, 512 slots, ~1000 TF)
+    int big = 0, small_ = 0;
+    for (int i = 0; i < nprob; ++i) { big += tiles(gg.p[i].M, gg.p[i].N, 256); small_ += tiles(gg.p[i].M, gg.p[i].N, 128); }
+    const float eff_big = (float)big / (float)(((big + 255) / 256) * 256);
+    const float eff_small = (float)small_ / (float)(((small_ + 511) / 512) * 512);
+    bool use_big = 1150.f * eff_big > 1000.f * eff_small;
+    const char* v = getenv("RGN_GEMM_VARIANT");
+    if (v && v[0] == '1') use_big = false;
+    if (v && v[0] == '2') use_big = true;
+    const int b = use_big ? 256 : 128;
+    gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
+    gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
+    if (gg.nt == 0) return 0;
+    return use_big ? launch_gemm<256, 256, 2, 4>(gg, epilogue, st) : launch_gemm<128, 128, 2, 2>(gg, epilogue, st);
+}
+
+static void fill(GemmArgs& g, const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M,
+                 int N, int K, int gelu_from_col, const void* gate, const void* resid, const int64_t* out_rows) {
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.bias = (const uint16_t*)bias; g.C = (uint16_t*)C;
     g.gate = (const uint16_t*)gate; g.resid = (const uint16_t*)resid; g.out_rows = out_rows;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.gelu_from_col = gelu_from_col;
-    const int nt = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const size_t lds = 2 * STAGE_BYTES;
-    hipStream_t st = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    switch (epilogue) {
-        case RGN_EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<RGN_EPI_BIAS>, dim3(nt), dim3(256), lds, st, g); break;
-        case RGN_EPI_GELU: hipLaunchKernelGGL(gemm_bf16_kernel<RGN_EPI_GELU>, dim3(nt), dim3(256), lds, st, g); break;
-        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL(gemm_bf16_kernel<RGN_EPI_GATE_RESID>, dim3(nt), dim3(256), lds, st, g); break;
-        default: return fail(RGN_E_BADARG, "gemm: unknown epilogue");
-    }
-    return check_launch("gemm_bf16_kernel");
+}
+
+extern "C" {
+
+int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
+                  int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
+                  const int64_t* out_rows, void* stream) {
+    if (M == 0) return 0;
+    int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, resid);
+    if (rc) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, gate, resid, out_rows);
+    gg.p[1] = gg.p[0];
+    return gemm_dispatch(gg, 1, epilogue, (hipStream_t)stream);
+}
+
+int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
+                       const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1,
+                       const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1, int N,
+                       int K, int epilogue, int gelu_from_col, void* stream) {
+    if (M0 == 0 && M1 == 0) return 0;
+    if (M0 == 0) return rgn_gemm_bf16(A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, epilogue, gelu_from_col, gate1, resid1, nullptr, stream);
+    if (M1 == 0) return rgn_gemm_bf16(A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, epilogue, gelu_from_col, gate0, resid0, nullptr, stream);
+    int rc = check_problem(A0, lda0, W0, K, C0, ldc0, M0, N, K, epilogue, gate0, resid0);
+    if (rc) return rc;
+    rc = check_problem(A1, lda1, W1, K, C1, ldc1, M1, N, K, epilogue, gate1, resid1);
+    if (rc) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, gelu_from_col, gate0, resid0, nullptr);
+    fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, gelu_from_col, gate1, resid1, nullptr);
+    return gemm_dispatch(gg, 2, epilogue, (hipStream_t)stream);
 }
 
 int rgn_gemv_bf16(const void* x, int ldx, const void* W, const void* bias, void* y, int ldy, int B, int N, int K,

@@ -224,16 +224,15 @@ class FluxAttnProcessor:
         k_slab, vt_slab, kv_rows, skv, rope_k = self.kv_target(attn, ctx)
         rope_k = rope_k if rope_k is not None else image_rotary_emb
         if not self.single:
-            ops.gemm(ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d])
-            ops.gemm(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d])
+            ops.gemm_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
+                          ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d])
             ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
                                    k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
             q = wide[:, 2 * d:3 * d]
             ops.attention(q, k_slab, vt_slab, q, skv, H)
             g_img, g_txt = block.gates_msa(ctx)
-            ops.gemm(q[T:R], attn.w_out, attn.b_out, ws.x[T:R], epilogue=ops.EPI_GATE_RESID, gate=g_img, resid=ws.x[T:R])
-            ops.gemm(q[:T], attn.w_add_out, attn.b_add_out, ws.x[:T], epilogue=ops.EPI_GATE_RESID, gate=g_txt,
-                     resid=ws.x[:T])
+            ops.gemm_pair(q[T:R], attn.w_out, attn.b_out, ws.x[T:R], q[:T], attn.w_add_out, attn.b_add_out, ws.x[:T],
+                          epilogue=ops.EPI_GATE_RESID, gate0=g_img, resid0=ws.x[T:R], gate1=g_txt, resid1=ws.x[:T])
             return ws.x[T:R], ws.x[:T]
         # single stream: one GEMM produces [k | v | q | gelu(mlp)] from the same normed activations
         ops.gemm(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * d)
@@ -270,12 +269,11 @@ class FluxTransformerBlock:
         ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo_img, 3), mods.chunk(self.mo_img, 4), split_row=T,
                         shift0=mods.chunk(self.mo_ctx, 3), scale0=mods.chunk(self.mo_ctx, 4))
         ffh = ws.wide[:R, 3 * d:]
-        ops.gemm(ws.nrm[T:R], self.ff_w1, self.ff_b1, ffh[T:R], epilogue=ops.EPI_GELU)
-        ops.gemm(ffh[T:R], self.ff_w2, self.ff_b2, ws.x[T:R], epilogue=ops.EPI_GATE_RESID,
-                 gate=mods.chunk(self.mo_img, 5), resid=ws.x[T:R])
-        ops.gemm(ws.nrm[:T], self.ffc_w1, self.ffc_b1, ffh[:T], epilogue=ops.EPI_GELU)
-        ops.gemm(ffh[:T], self.ffc_w2, self.ffc_b2, ws.x[:T], epilogue=ops.EPI_GATE_RESID,
-                 gate=mods.chunk(self.mo_ctx, 5), resid=ws.x[:T])
+        ops.gemm_pair(ws.nrm[T:R], self.ff_w1, self.ff_b1, ffh[T:R], ws.nrm[:T], self.ffc_w1, self.ffc_b1, ffh[:T],
+                      epilogue=ops.EPI_GELU)
+        ops.gemm_pair(ffh[T:R], self.ff_w2, self.ff_b2, ws.x[T:R], ffh[:T], self.ffc_w2, self.ffc_b2, ws.x[:T],
+                      epilogue=ops.EPI_GATE_RESID, gate0=mods.chunk(self.mo_img, 5), resid0=ws.x[T:R],
+                      gate1=mods.chunk(self.mo_ctx, 5), resid1=ws.x[:T])
         return ws.x[:T], ws.x[T:R]
 
 

@@ -153,6 +153,21 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: to
     return out
 
 
+def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, gelu_from_col: int = 0,
+              gate0=None, resid0=None, gate1=None, resid1=None):
+    """Two GEMMs with equal (N, K) and epilogue in one launch: outI = epilogue(AI @ WI^T + bI)."""
+    N, K = W0.shape
+    assert W1.shape == (N, K) and W0.is_contiguous() and W1.is_contiguous()
+    assert A0.shape[1] == K and A1.shape[1] == K and out0.shape[1] == N and out1.shape[1] == N
+    for t in (A0, A1, out0, out1):
+        assert t.stride(1) == 1 and t.dtype == torch.bfloat16
+    rc = _lib.lib().rgn_gemm_bf16_pair(_p(A0), A0.stride(0), _p(W0), _p(b0), _p(out0), out0.stride(0), A0.shape[0],
+                                       _p(gate0), _p(resid0), _p(A1), A1.stride(0), _p(W1), _p(b1), _p(out1),
+                                       out1.stride(0), A1.shape[0], _p(gate1), _p(resid1), N, K, epilogue,
+                                       gelu_from_col, _stream())
+    _lib.check(rc, "rgn_gemm_bf16_pair")
+
+
 def gemv(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], silu_input: bool = False,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, K = x.shape

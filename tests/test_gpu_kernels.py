@@ -21,10 +21,12 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 256, 192), (1, 128, 64), (1000, 64, 3072),
                                    (777, 200, 128), (8704, 3072, 3072)])
-def test_gemm_bias(M, N, K):
+def test_gemm_bias(M, N, K, variant, monkeypatch):
     from regione_amd import ops
+    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)          # 1 = 128x128 tiles, 2 = 256x256 tiles
     g = torch.Generator().manual_seed(M * 7 + N)
     # asymmetric operands so a transposed C-write cannot pass (guide rule 16)
     A = bf(torch.randn(M, K, generator=g))
@@ -77,6 +79,34 @@ def test_gemm_strided_views_scatter_and_epilogues():
     untouched[idx] = False
     assert torch.equal(cache.cpu()[untouched], c0[untouched])
     assert rel_err(cache.cpu()[idx], ref[idx]) < 3e-3
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_gemm_pair_two_problems_one_launch(variant, monkeypatch):
+    from regione_amd import ops
+    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    g = torch.Generator().manual_seed(9)
+    N, K, M0, M1 = 384, 256, 700, 90
+    A0, A1 = bf(torch.randn(M0, K, generator=g)).cuda(), bf(torch.randn(M1, K, generator=g)).cuda()
+    W0, W1 = bf(torch.randn(N, K, generator=g) * 0.1).cuda(), bf(torch.randn(N, K, generator=g) * 0.1).cuda()
+    b0, b1 = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+    g0, g1 = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+    r0, r1 = bf(torch.randn(M0, N, generator=g)).cuda(), bf(torch.randn(M1, N, generator=g)).cuda()
+    o0, o1 = torch.empty_like(r0), torch.empty_like(r1)
+    ops.gemm_pair(A0, W0, b0, o0, A1, W1, b1, o1)
+    s0, s1 = torch.empty_like(r0), torch.empty_like(r1)
+    ops.gemm(A0, W0, b0, s0)
+    ops.gemm(A1, W1, b1, s1)
+    assert torch.equal(o0, s0) and torch.equal(o1, s1)          # identical to two separate launches
+    ref0 = F.linear(A0.cpu().double(), W0.cpu().double(), b0.cpu().double())
+    assert rel_err(o0.cpu(), ref0) < 3e-3
+    # gated residual, in place, both problems
+    x0, x1 = r0.clone(), r1.clone()
+    ops.gemm_pair(A0, W0, b0, x0, A1, W1, b1, x1, epilogue=ops.EPI_GATE_RESID, gate0=g0, resid0=x0, gate1=g1, resid1=x1)
+    y0, y1 = r0.clone(), r1.clone()
+    ops.gemm(A0, W0, b0, y0, epilogue=ops.EPI_GATE_RESID, gate=g0, resid=y0)
+    ops.gemm(A1, W1, b1, y1, epilogue=ops.EPI_GATE_RESID, gate=g1, resid=y1)
+    assert torch.equal(x0, y0) and torch.equal(x1, y1)
 
 
 @pytest.mark.parametrize("B,N,K,silu", [(1, 18432, 3072, True), (2, 1000, 256, False), (1, 3072, 768, False)])

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the dominant kernels at the FLUX 1024^2 shapes (GPU box only).
+    python tools/bench_kernels.py [gemm] [attn] [gemv]
+Reports TFLOP/s (algorithmic) per shape, median of N interleaved rounds, uniform random [-1,1) data."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from regione_amd import ops
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def rnd(*shape):
+    return (torch.rand(*shape, device="cuda") * 2 - 1).to(torch.bfloat16)
+
+
+def bench_gemm():
+    shapes = [("single kvq+mlp", 8704, 21504, 3072), ("single proj_out", 8704, 3072, 15360),
+              ("double img qkv", 8192, 9216, 3072), ("double img out", 8192, 3072, 3072),
+              ("double img ff1", 8192, 12288, 3072), ("double img ff2", 8192, 3072, 12288),
+              ("double txt qkv", 512, 9216, 3072), ("double txt ff2", 512, 3072, 12288),
+              ("region kvq+mlp", 1536, 21504, 3072), ("region proj_out", 1536, 3072, 15360),
+              ("region img out", 1024, 3072, 3072), ("square 8192", 8192, 8192, 8192)]
+    for name, M, N, K in shapes:
+        A, W, b = rnd(M, K), rnd(N, K) * 0.05, rnd(N)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        for variant in VARIANTS:
+            os.environ["RGN_GEMM_VARIANT"] = variant
+            med, best = timeit(lambda: ops.gemm(A, W, b, out))
+            fl = 2.0 * M * N * K
+            print(f"gemm[{variant:>4}] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
+        del A, W, out
+
+
+def bench_attn():
+    for name, Sq, Skv, H in [("full", 8704, 8704, 24), ("region 25%", 1536, 8704, 24), ("region 5%", 717, 8704, 24)]:
+        D = H * 128
+        q, k, vt = rnd(Sq, D), rnd(Skv, D), rnd(D, Skv)
+        out = torch.empty_like(q)
+        for variant in AVARIANTS:
+            os.environ["RGN_ATTN_VARIANT"] = variant
+            med, best = timeit(lambda: ops.attention(q, k, vt, out, Skv, H))
+            fl = 4.0 * Sq * Skv * D
+            print(f"attn[{variant:>4}] {name:<12} Sq={Sq:<5} Skv={Skv:<5} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
+
+
+def bench_gemv():
+    N, K = 1056768, 3072
+    W, b, x = rnd(N, K), rnd(N), rnd(1, K)
+    med, best = timeit(lambda: ops.gemv(x, W, b, silu_input=True), iters=5)
+    print(f"gemv modulation N={N} K={K}: {med*1e3:.1f} us  {N*K*2/med/1e9:.2f} TB/s")
+
+
+VARIANTS = os.environ.get("GEMM_VARIANTS", "auto").split(",")
+AVARIANTS = os.environ.get("ATTN_VARIANTS", "auto").split(",")
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "attn", "gemv"]
+    if "gemm" in which: bench_gemm()
+    if "attn" in which: bench_attn()
+    if "gemv" in which: bench_gemv()
