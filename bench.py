@@ -55,6 +55,16 @@ class KernelTimer:
 
     def __init__(self):
         self.rec = {}
+        self.shapes = {}
+
+    def shape_table(self, top=10):
+        rows = []
+        for (m0, m1, n, k), lst in self.shapes.items():
+            ms = sum(s.elapsed_time(e) for s, e in lst)
+            rows.append(dict(M=[m0, m1], N=n, K=k, launches=len(lst), total_ms=round(ms, 2),
+                             tflops=round(2.0 * (m0 + m1) * n * k * len(lst) / (ms * 1e-3) / 1e12, 1)))
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows[:top]
 
     def wrap(self, ops_mod):
         import regione_amd.ops as ops
@@ -68,6 +78,7 @@ class KernelTimer:
             r = timer._orig_pair(A0, W0, b0, o0, A1, W1, b1, o1, **kw)
             e.record()
             timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (A0.shape[0] + A1.shape[0]) * N * K))
+            timer.shapes.setdefault((A0.shape[0], A1.shape[0], N, K), []).append((s, e))
             return r
 
         def gemm(A, W, bias, out, **kw):
@@ -78,6 +89,7 @@ class KernelTimer:
             r = timer._orig_gemm(A, W, bias, out, **kw)
             e.record()
             timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * M * N * K))
+            timer.shapes.setdefault((M, 0, N, K), []).append((s, e))
             return r
 
         def attention(q, k_slab, vt_slab, out, skv, H, scale=None):
@@ -323,6 +335,7 @@ def main():
                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
                               "traffic": None, "launches": k["launches"], "avg_launch_us": k["avg_us"],
                               "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
+    result["gemm_shapes"] = timer.shape_table()
     if "attention_kernel" in ksum:
         k = ksum["attention_kernel"]
         result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_kernel", "achieved": k["achieved_tflops"],

@@ -120,6 +120,9 @@ int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bia
 int rgn_gemv_bf16(const void* x, int ldx, const void* W, const void* bias, void* y, int ldy, int B, int N,
                   int K, int silu_input, void* stream);
 
+/* y = bf16(silu(x)) elementwise on bf16 (F.silu of the AdaLN conditioning vector). */
+int rgn_silu_bf16(const void* x, void* y, size_t n, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm(eps, no affine) * (1 + scale) + shift over rows of width d (AdaLN-Zero modulate).
  * Rows < split_row use (shift0, scale0), the others (shift1, scale1) - the text / image streams
@@ -151,10 +154,16 @@ int rgn_qk_norm_rope_store(void* qkv, int ld, int k_col, int v_col, int q_col, i
  * flash_attn_func / SDPA (inplace.py:796-806).  softmax(Q K^T / sqrt(128)) V, non-causal,
  * Sq != Skv allowed, head_dim 128, fp32 online softmax, bf16 MFMA.
  *   Q [Sq, H*128] (row stride ldq) ; K slab / V^T slab as written by rgn_qk_norm_rope_store;
- *   O [Sq, H*128] (row stride ldo), may alias Q (each workgroup reads its Q tile before writing).
+ *   O [Sq, H*128] (row stride ldo), may alias Q (each workgroup reads its Q tile before writing;
+ *   with a workspace, split items write O only in the final combine pass).
  */
 int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O,
-                  int ldo, int Sq, int Skv, int H, float scale, void* stream);
+                  int ldo, int Sq, int Skv, int H, float scale, void* workspace, size_t workspace_bytes,
+                  void* stream);
+/* Optional fp32 scratch for the round-aware schedule: (head, q-block) items that do not fill a whole
+ * round of the chip's workgroup slots are cut along KV and merged by a combine kernel.  NULL disables
+ * the split (results are identical up to fp32 summation order). */
+size_t rgn_attention_workspace_bytes(int Sq, int H);
 
 /* Device properties the host side needs for roofline reporting (no torch types). */
 int rgn_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes);

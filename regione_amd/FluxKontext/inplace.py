@@ -115,6 +115,9 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
         MANAGER.refresh(latents, image_latents, latent_ids, text_ids, 2, self.vae_scale_factor, height, width)
         avd, cache = AvdState(), None
         self.scheduler.set_begin_index(0)
+        if hasattr(self.transformer, "precompute_modulations"):
+            self.transformer.precompute_modulations([t.expand(1).to(latents.dtype) / 1000 for t in timesteps], guidance,
+                                                    pooled_prompt_embeds)
         for i, t in enumerate(timesteps):
             assert i == MANAGER.current_step
             should_cache, ratio = avd_decide(MANAGER, avd, i, timesteps)

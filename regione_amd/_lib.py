@@ -38,15 +38,17 @@ SIGNATURES = {
                            _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "rgn_gemv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_void_p],
+    "rgn_silu_bf16": [_c_void_p, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_ln_modulate": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "rgn_qk_norm_rope_store": [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                                _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
                                _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "rgn_attention": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                      _c_float, _c_void_p],
+                      _c_float, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_attention_workspace_bytes": [_c_int, _c_int],
 }
-_RESTYPE = {"rgn_last_error": C.c_char_p}
+_RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_attention_workspace_bytes": C.c_size_t}
 
 _lib = None
 

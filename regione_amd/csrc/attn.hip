@@ -38,6 +38,10 @@ struct AttnArgs {
     uint16_t* O;
     int ldq, ldo, skv_pad, Sq, Skv, H;
     float scale_log2e;
+    // round-aware launch: this launch covers items [item_offset, item_offset + nitems_launch); in
+    // SPLIT mode every item is cut into nsplit KV ranges whose partial (O, m, l) go to `ws`.
+    int item_offset, nitems_launch, nsplit;
+    float* ws;
 };
 
 constexpr int KV_T = 64;                       // kv rows per tile
@@ -56,7 +60,7 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int NW, int NSTAGE, int ABL = 0>
+template <int NW, int NSTAGE, bool SPLIT>
 __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(const AttnArgs g) {
     constexpr int QB = 32 * NW;                 // query rows per workgroup
     constexpr int PW = 16 / NW;                 // K pieces (= V pieces) per wave per stage
@@ -66,12 +70,15 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
     const int ql = lane & 31, half = lane >> 5;
 
     // ---- XCD-aware bijective item map: item = head * nQ + qblock ---------------------------------
-    const int nQ = (g.Sq + QB - 1) / QB, nitems = g.H * nQ;
-    int item;
+    const int nQ = (g.Sq + QB - 1) / QB;
+    int item, split = 0;
     {
+        const int nb = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
         const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-        const int q = nitems >> 3, r = nitems & 7;
-        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int q = nb >> 3, r = nb & 7;
+        int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if (SPLIT) { split = u % g.nsplit; u /= g.nsplit; }
+        item = g.item_offset + u;
     }
     const int h = item / nQ, qb = item - h * nQ;
     const int q0 = qb * QB + wave * 32;
@@ -129,10 +136,16 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
     float l_run = 0.f;
     const float sl2e = g.scale_log2e;
 
-    const int ntiles = (g.Skv + KV_T - 1) / KV_T;
+    const int ntiles_all = (g.Skv + KV_T - 1) / KV_T;
+    int t_begin = 0, ntiles = ntiles_all;
+    if (SPLIT) {
+        const int per = (ntiles_all + g.nsplit - 1) / g.nsplit;
+        t_begin = split * per;
+        ntiles = max(0, min(per, ntiles_all - t_begin));
+    }
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < ntiles) stage(s, s);
+        if (s < ntiles) stage(t_begin + s, s);
     int cur = 0, nxt = NSTAGE - 1;
     for (int t = 0; t < ntiles; ++t) {
         // tile t landed for this wave: leave the newer stages (at most NSTAGE-2) in flight
@@ -141,8 +154,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
         else if (NSTAGE >= 3 && newer == 1) wait_vm<2 * PW>();
         else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
-        if (ABL != 4 && t + NSTAGE - 1 < ntiles) stage(t + NSTAGE - 1, nxt);
-        const uint8_t* sb = smem + ((ABL == 4) ? 0 : cur) * ATT_STAGE;
+        if (t + NSTAGE - 1 < ntiles) stage(t_begin + t + NSTAGE - 1, nxt);
+        const uint8_t* sb = smem + cur * ATT_STAGE;
         cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
         nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
 
@@ -153,13 +166,13 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const int sl = ((ks * 2 + half) ^ k_sw) << 4;
-            const bf8_t kf0 = (ABL == 5) ? qf[(ks + 1) & 7] : *(const bf8_t*)(sb + k_row_off + sl);
-            const bf8_t kf1 = (ABL == 5) ? qf[(ks + 2) & 7] : *(const bf8_t*)(sb + 32 * 256 + k_row_off + sl);
+            const bf8_t kf0 = *(const bf8_t*)(sb + k_row_off + sl);
+            const bf8_t kf1 = *(const bf8_t*)(sb + 32 * 256 + k_row_off + sl);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
         }
         // ---- tail mask ---------------------------------------------------------------------------
-        const int kv0 = t * KV_T;
+        const int kv0 = (t_begin + t) * KV_T;
         if (kv0 + KV_T > g.Skv) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -169,10 +182,6 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
             }
         }
         // ---- online softmax with deferred max -------------------------------------------------------
-        if (ABL == 3) {   // ablation: no QK^T result dependence (keep MFMAs alive)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { asm volatile("" ::"v"(s0[r]), "v"(s1[r])); }
-        }
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
@@ -193,11 +202,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
             float p0[16], p1[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                if (ABL == 1) { p0[r] = s0[r]; p1[r] = s1[r]; }      // ablation: no exp
-                else {
-                    p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2e, -m_run));
-                    p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2e, -m_run));
-                }
+                p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2e, -m_run));
+                p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2e, -m_run));
                 psum += p0[r] + p1[r];
             }
 #pragma unroll
@@ -213,25 +219,36 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
             }
         }
         l_run += psum;
-        if (ABL == 2) {    // ablation: no PV MFMAs (keep P alive)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(pf[k]));
-            continue;
-        }
         // ---- O^T += V^T P^T : 4 k-blocks x 4 d-blocks (independent accumulators back to back) -------
 #pragma unroll
         for (int kb4 = 0; kb4 < 4; ++kb4) {
             const int sl = ((kb4 * 2 + half) ^ v_sw) << 4;
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
-                const bf8_t vf = (ABL == 5) ? qf[(db + kb4) & 7] : *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + sl);
+                const bf8_t vf = *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + sl);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb4], o[db], 0, 0, 0);
             }
         }
     }
 
-    // ---- finalize: O = O^T / l, staged through LDS for 16-byte row-contiguous stores ----------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (SPLIT) {
+        // partial result of this KV range: unnormalised O (fp32), running max (scaled-log2 units), row sum
+        float* base = g.ws + ((size_t)(item - g.item_offset) * g.nsplit + split) * (size_t)(QB * 130);
+        float* orow = base + (size_t)(wave * 32 + ql) * 128;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                *(float4*)(orow + db * 32 + 8 * r4 + 4 * half) =
+                    make_float4(o[db][r4 * 4 + 0], o[db][r4 * 4 + 1], o[db][r4 * 4 + 2], o[db][r4 * 4 + 3]);
+        if (half == 0) {
+            base[QB * 128 + wave * 32 + ql] = m_run;
+            base[QB * 129 + wave * 32 + ql] = l_tot;
+        }
+        return;
+    }
+    // ---- finalize: O = O^T / l, staged through LDS for 16-byte row-contiguous stores ----------------
     const float inv = 1.0f / l_tot;
     constexpr int OT_LD = 136;
     constexpr int OCHUNK = (NSTAGE * ATT_STAGE >= QB * OT_LD * 2) ? 1 : 2;     // O tile may need two passes
@@ -264,461 +281,85 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Software-pipelined variant (T15 "compute[next] || finish[cur]"): inside ONE wave the 16 QK^T MFMAs
-// of tile t+1 are issued in the same basic block as the softmax VALU work of tile t, so the matrix
-// pipe runs under the exp/pack stream instead of idling behind it (all waves of a workgroup are
-// re-aligned by the per-tile barrier, so cross-wave staggering alone cannot provide that overlap).
-// Ring of 3 stages: K(t+1) and V(t) are live while tile t+2 streams in.
-// ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_pipe_kernel(const AttnArgs g) {
-    constexpr int NSTAGE = 3;
-    constexpr int QB = 32 * NW;
-    constexpr int PW = 16 / NW;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 31, half = lane >> 5;
-    const int nQ = (g.Sq + QB - 1) / QB, nitems = g.H * nQ;
-    int item;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-        const int q = nitems >> 3, r = nitems & 7;
-        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
+// Merge the nsplit partial results of each split item: O = sum_s O_s 2^(m_s - m*) / sum_s l_s 2^(m_s - m*).
+template <int QB>
+__global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g) {
+    const int nQ = (g.Sq + QB - 1) / QB;
+    const int u = blockIdx.x / (QB / 16);                       // split item index
+    const int row = (blockIdx.x % (QB / 16)) * 16 + (threadIdx.x >> 4);
+    const int c = (threadIdx.x & 15) * 8;
+    const int item = g.item_offset + u;
     const int h = item / nQ, qb = item - h * nQ;
-    const int q0 = qb * QB + wave * 32;
-    const size_t HD = (size_t)g.H * 128;
-
-    bf8_t qf[8];
-    {
-        const int qr = min(q0 + ql, g.Sq - 1);
-        const uint16_t* qp = g.Q + (size_t)qr * g.ldq + h * 128 + half * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf8_t*)(qp + ks * 16);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
+    const int qr = qb * QB + row;
+    if (qr >= g.Sq) return;
+    const float* base = g.ws + (size_t)u * g.nsplit * (size_t)(QB * 130);
+    float mstar = -1e30f;
+    for (int s = 0; s < g.nsplit; ++s) mstar = fmaxf(mstar, base[(size_t)s * QB * 130 + QB * 128 + row]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int s = 0; s < g.nsplit; ++s) {
+        const float* b = base + (size_t)s * QB * 130;
+        const float w = __builtin_amdgcn_exp2f(b[QB * 128 + row] - mstar);
+        l += b[QB * 129 + row] * w;
+        const float4 x0 = *(const float4*)(b + (size_t)row * 128 + c), x1 = *(const float4*)(b + (size_t)row * 128 + c + 4);
+        acc[0] += x0.x * w; acc[1] += x0.y * w; acc[2] += x0.z * w; acc[3] += x0.w * w;
+        acc[4] += x1.x * w; acc[5] += x1.y * w; acc[6] += x1.z * w; acc[7] += x1.w * w;
     }
-    const uint8_t* k_src[PW];
-    const uint8_t* v_src[PW];
-#pragma unroll
-    for (int p = 0; p < PW; ++p) {
-        const int piece = wave * PW + p;
-        const int krow = piece * 4 + (lane >> 4);
-        const int kchunk = (lane & 15) ^ (krow & 15);
-        k_src[p] = (const uint8_t*)(g.K + (size_t)krow * HD + h * 128) + kchunk * 16;
-        const int vrow = piece * 8 + (lane >> 3);
-        const int vchunk = (lane & 7) ^ ((vrow >> 1) & 7);
-        v_src[p] = (const uint8_t*)(g.Vt + ((size_t)h * 128 + vrow) * g.skv_pad) + vchunk * 16;
-    }
-    auto stage = [&](int t, int buf) {
-        uint8_t* base = smem + buf * ATT_STAGE + (wave * PW) * 1024;
-        const size_t koff = (size_t)t * KV_T * HD * 2, voff = (size_t)t * KV_T * 2;
-#pragma unroll
-        for (int p = 0; p < PW; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(k_src[p] + koff), (lds_ptr_t)(base + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(v_src[p] + voff),
-                                             (lds_ptr_t)(base + K_TILE_BYTES + p * 1024), 16, 0, 0);
-        }
-    };
-    const int k_row_off = ql * 256, k_sw = ql & 15;
-    const int v_row_off = K_TILE_BYTES + ql * 128, v_sw = (ql >> 1) & 7;
-
-    f32x16 o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float sl2e = g.scale_log2e;
-    const int ntiles = (g.Skv + KV_T - 1) / KV_T;
-
-    auto qk = [&](const uint8_t* sb, f32x16& s0, f32x16& s1) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int sl = ((ks * 2 + half) ^ k_sw) << 4;
-            const bf8_t kf0 = *(const bf8_t*)(sb + k_row_off + sl);
-            const bf8_t kf1 = *(const bf8_t*)(sb + 32 * 256 + k_row_off + sl);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
-        }
-    };
-
-    stage(0, 0);
-    if (ntiles > 1) stage(1, 1);
-    if (ntiles > 1) wait_vm<2 * PW>(); else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    f32x16 c0, c1;                                   // S^T of the current tile
-    qk(smem, c0, c1);
-    // tile-0 mask + running-max initialisation (the loop always enters with m_run valid for c0/c1)
-    auto tile_max = [&](int t, f32x16& a0, f32x16& a1) -> float {
-        const int kv0 = t * KV_T;
-        if (kv0 + KV_T > g.Skv) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (kv >= g.Skv) a0[r] = -INFINITY;
-                if (kv + 32 >= g.Skv) a1[r] = -INFINITY;
-            }
-        }
-        float mx = fmaxf(a0[0], a1[0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(a0[r], a1[r]));
-        return fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;
-    };
-    auto raise_max = [&](float mx) {
-        if (__any(mx > m_run + DEFER_THR)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-    };
-    raise_max(tile_max(0, c0, c1));
-    int cur = 0;
-    for (int t = 0; t < ntiles; ++t) {
-        const int nb = (cur + 1 == NSTAGE) ? 0 : cur + 1;          // buffer of tile t+1
-        const int lb = (nb + 1 == NSTAGE) ? 0 : nb + 1;            // buffer of tile t+2 (= tile t-1's)
-        wait_vm<0>();                                              // tile t+1 (issued one iteration ago) landed
-        __builtin_amdgcn_s_barrier();                              // ... for every wave; PV(t-1) finished everywhere
-        if (t + 2 < ntiles) stage(t + 2, lb);
-        const uint8_t* sb = smem + cur * ATT_STAGE;
-        // ---- block 1: QK^T of tile t+1 (MFMA + LDS) interleaved with exp/pack of tile t (VALU) -------
-        // (on the last tile the QK^T runs on a stale buffer and its result is discarded)
-        f32x16 n0, n1;
-        qk(smem + nb * ATT_STAGE, n0, n1);
-        float psum = 0.f;
-        bf8_t pf[4];
-        {
-            float p0[16], p1[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(c0[r], sl2e, -m_run));
-                p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(c1[r], sl2e, -m_run));
-                psum += p0[r] + p1[r];
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                uint32_t w0[4], w1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    w0[j] = cvt_pk_bf16(p0[kb * 8 + 2 * j], p0[kb * 8 + 2 * j + 1]);
-                    w1[j] = cvt_pk_bf16(p1[kb * 8 + 2 * j], p1[kb * 8 + 2 * j + 1]);
-                }
-                pf[kb] = *(bf8_t*)w0;
-                pf[2 + kb] = *(bf8_t*)w1;
-            }
-        }
-        l_run += psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
-            __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);     // 9 VALU (incl. transcendental)
-        }
-        // ---- block 2: PV of tile t (MFMA + LDS) interleaved with the row max of tile t+1 (VALU) ------
-#pragma unroll
-        for (int kb4 = 0; kb4 < 4; ++kb4) {
-            const int sl = ((kb4 * 2 + half) ^ v_sw) << 4;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const bf8_t vf = *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + sl);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb4], o[db], 0, 0, 0);
-            }
-        }
-        float mxn = -1e30f;
-        if (t + 1 < ntiles) mxn = tile_max(t + 1, n0, n1);
-        raise_max(mxn);
-        c0 = n0; c1 = n1;
-        cur = nb;
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    constexpr int OT_LD = 136;
-    uint16_t* ot = (uint16_t*)smem;                    // 3 stages = 96 KiB >= 256 x 136 x 2
-    __syncthreads();
-    {
-        uint16_t* orow = ot + (wave * 32 + ql) * OT_LD;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = db * 32 + 8 * r4 + 4 * half;
-                const uint32_t w0 = cvt_pk_bf16(o[db][r4 * 4 + 0] * inv, o[db][r4 * 4 + 1] * inv);
-                const uint32_t w1 = cvt_pk_bf16(o[db][r4 * 4 + 2] * inv, o[db][r4 * 4 + 3] * inv);
-                *(uint2*)(orow + d) = make_uint2(w0, w1);
-            }
-    }
-    __syncthreads();
-    constexpr int RPP = (64 * NW) / 16;
-#pragma unroll
-    for (int it = 0; it < QB / RPP; ++it) {
-        const int row = (tid >> 4) + it * RPP, c = (tid & 15) * 8;
-        const int qr = qb * QB + row;
-        if (qr < g.Sq) *(uint4*)(g.O + (size_t)qr * g.ldo + h * 128 + c) = *(const uint4*)(ot + row * OT_LD + c);
-    }
+    const float inv = 1.0f / l;
+    uint4 out;
+    out.x = cvt_pk_bf16(acc[0] * inv, acc[1] * inv); out.y = cvt_pk_bf16(acc[2] * inv, acc[3] * inv);
+    out.z = cvt_pk_bf16(acc[4] * inv, acc[5] * inv); out.w = cvt_pk_bf16(acc[6] * inv, acc[7] * inv);
+    *(uint4*)(g.O + (size_t)qr * g.ldo + h * 128 + c) = out;
 }
 
-template <int NW>
-static int launch_attention_pipe(const AttnArgs& g, hipStream_t st) {
-    constexpr int QB = 32 * NW;
-    const int nitems = g.H * ((g.Sq + QB - 1) / QB);
-    constexpr int LDS = 3 * ATT_STAGE;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attention_pipe_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
-    hipLaunchKernelGGL((attention_pipe_kernel<NW>), dim3(nitems), dim3(64 * NW), LDS, st, g);
-    return check_launch("attention_pipe_kernel");
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ping-pong variant: the two waves that share a SIMD (wave w and w + NW/2) run the three per-tile
-// phases  QK^T (matrix) -> softmax (VALU) -> PV (matrix)  ONE PHASE APART, separated by workgroup
-// barriers, so that a SIMD's matrix pipe and its VALU are busy at the same time:
-//      interval 1:  A: QK(t)   | B: PV(t-1)        (matrix | matrix)
-//      interval 2:  A: SM(t)   | B: QK(t)          (VALU   | matrix)
-//      interval 3:  A: PV(t)   | B: SM(t)          (matrix | VALU)
-// A lock-step workgroup (every wave in the same phase, re-aligned by the per-tile barrier) measured
-// 3780 cycles per tile per SIMD = MFMA (2048) + VALU (~1800) fully serialised (rocprofv3 PMC:
-// SQ_WAVE_CYCLES vs SQ_VALU_MFMA_BUSY_CYCLES); the one-phase skew lets them overlap.
-// Ring of 3 K/V stages: tile t-1 (B's PV), tile t, tile t+1 landing.
-// ------------------------------------------------------------------------------------------------
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void attention_pp_kernel(const AttnArgs g) {
-    constexpr int NSTAGE = 3;
-    constexpr int QB = 32 * NW;
-    constexpr int PW = 16 / NW;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool grpB = wave >= NW / 2;
-    const int ql = lane & 31, half = lane >> 5;
-    const int nQ = (g.Sq + QB - 1) / QB, nitems = g.H * nQ;
-    int item;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-        const int q = nitems >> 3, r = nitems & 7;
-        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int h = item / nQ, qb = item - h * nQ;
-    const int q0 = qb * QB + wave * 32;
-    const size_t HD = (size_t)g.H * 128;
-
-    bf8_t qf[8];
-    {
-        const int qr = min(q0 + ql, g.Sq - 1);
-        const uint16_t* qp = g.Q + (size_t)qr * g.ldq + h * 128 + half * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *(const bf8_t*)(qp + ks * 16);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) asm volatile("" : "+v"(qf[ks]));
-    }
-    const uint8_t* k_src[PW];
-    const uint8_t* v_src[PW];
-#pragma unroll
-    for (int p = 0; p < PW; ++p) {
-        const int piece = wave * PW + p;
-        const int krow = piece * 4 + (lane >> 4);
-        const int kchunk = (lane & 15) ^ (krow & 15);
-        k_src[p] = (const uint8_t*)(g.K + (size_t)krow * HD + h * 128) + kchunk * 16;
-        const int vrow = piece * 8 + (lane >> 3);
-        const int vchunk = (lane & 7) ^ ((vrow >> 1) & 7);
-        v_src[p] = (const uint8_t*)(g.Vt + ((size_t)h * 128 + vrow) * g.skv_pad) + vchunk * 16;
-    }
-    auto stage = [&](int t, int buf) {
-        uint8_t* base = smem + buf * ATT_STAGE + (wave * PW) * 1024;
-        const size_t koff = (size_t)t * KV_T * HD * 2, voff = (size_t)t * KV_T * 2;
-#pragma unroll
-        for (int p = 0; p < PW; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(k_src[p] + koff), (lds_ptr_t)(base + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(v_src[p] + voff),
-                                             (lds_ptr_t)(base + K_TILE_BYTES + p * 1024), 16, 0, 0);
-        }
-    };
-    const int k_row_off = ql * 256, k_sw = ql & 15;
-    const int v_row_off = K_TILE_BYTES + ql * 128, v_sw = (ql >> 1) & 7;
-
-    f32x16 o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
-    const float sl2e = g.scale_log2e;
-    const int ntiles = (g.Skv + KV_T - 1) / KV_T;
-    f32x16 s0, s1;
-    bf8_t pf[4];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-
-    auto qk = [&](const uint8_t* sb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int sl = ((ks * 2 + half) ^ k_sw) << 4;
-            const bf8_t kf0 = *(const bf8_t*)(sb + k_row_off + sl);
-            const bf8_t kf1 = *(const bf8_t*)(sb + 32 * 256 + k_row_off + sl);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
-        }
-    };
-    auto sm = [&](int t) {
-        const int kv0 = t * KV_T;
-        if (kv0 + KV_T > g.Skv) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (kv >= g.Skv) s0[r] = -INFINITY;
-                if (kv + 32 >= g.Skv) s1[r] = -INFINITY;
-            }
-        }
-        float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;
-        if (__any(mx > m_run + DEFER_THR)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        float psum = 0.f;
-        float p0[16], p1[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2e, -m_run));
-            p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2e, -m_run));
-            psum += p0[r] + p1[r];
-        }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            uint32_t w0[4], w1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                w0[j] = cvt_pk_bf16(p0[kb * 8 + 2 * j], p0[kb * 8 + 2 * j + 1]);
-                w1[j] = cvt_pk_bf16(p1[kb * 8 + 2 * j], p1[kb * 8 + 2 * j + 1]);
-            }
-            pf[kb] = *(bf8_t*)w0;
-            pf[2 + kb] = *(bf8_t*)w1;
-        }
-        l_run += psum;
-    };
-    auto pv = [&](const uint8_t* sb) {
-#pragma unroll
-        for (int kb4 = 0; kb4 < 4; ++kb4) {
-            const int sl = ((kb4 * 2 + half) ^ v_sw) << 4;
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const bf8_t vf = *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + sl);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb4], o[db], 0, 0, 0);
-            }
-        }
-    };
-
-    stage(0, 0);
-    if (ntiles > 1) stage(1, 1);
-    // Two copies of the tile loop (one per wave group) with IDENTICAL barrier counts: separate loops
-    // keep each group's live ranges simple (one merged loop with per-interval branches spilled).
-    if (!grpB) {
-        int cur = 0, prev = NSTAGE - 1;             // buffers of tile t and tile t-1
-        for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) wait_vm<2 * PW>(); else wait_vm<0>();  // tile t landed (t+1 may be in flight)
-            __builtin_amdgcn_s_barrier();
-            const uint8_t* sb = smem + cur * ATT_STAGE;
-            qk(sb);                                                    // interval 1
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < ntiles) stage(t + 2, prev);                    // tile t-1's buffer is free now
-            sm(t);                                                     // interval 2
-            __builtin_amdgcn_s_barrier();
-            pv(sb);                                                    // interval 3
-            prev = cur;
-            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-        }
-    } else {
-        int cur = 0, prev = NSTAGE - 1;
-        for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) wait_vm<2 * PW>(); else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            if (t > 0) pv(smem + prev * ATT_STAGE);                    // interval 1: PV(t-1)
-            __builtin_amdgcn_s_barrier();
-            if (t + 2 < ntiles) stage(t + 2, prev);
-            qk(smem + cur * ATT_STAGE);                                // interval 2
-            __builtin_amdgcn_s_barrier();
-            sm(t);                                                     // interval 3
-            prev = cur;
-            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-        }
-        pv(smem + prev * ATT_STAGE);                                   // B's last PV
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    constexpr int OT_LD = 136;
-    uint16_t* ot = (uint16_t*)smem;                    // 3 stages = 96 KiB >= 256 x 136 x 2
-    __syncthreads();
-    {
-        uint16_t* orow = ot + (wave * 32 + ql) * OT_LD;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int d = db * 32 + 8 * r4 + 4 * half;
-                const uint32_t w0 = cvt_pk_bf16(o[db][r4 * 4 + 0] * inv, o[db][r4 * 4 + 1] * inv);
-                const uint32_t w1 = cvt_pk_bf16(o[db][r4 * 4 + 2] * inv, o[db][r4 * 4 + 3] * inv);
-                *(uint2*)(orow + d) = make_uint2(w0, w1);
-            }
-    }
-    __syncthreads();
-    constexpr int RPP = (64 * NW) / 16;
-#pragma unroll
-    for (int it = 0; it < QB / RPP; ++it) {
-        const int row = (tid >> 4) + it * RPP, c = (tid & 15) * 8;
-        const int qr = qb * QB + row;
-        if (qr < g.Sq) *(uint4*)(g.O + (size_t)qr * g.ldo + h * 128 + c) = *(const uint4*)(ot + row * OT_LD + c);
-    }
-}
-
-template <int NW>
-static int launch_attention_pp(const AttnArgs& g, hipStream_t st) {
-    constexpr int QB = 32 * NW;
-    const int nitems = g.H * ((g.Sq + QB - 1) / QB);
-    constexpr int LDS = 3 * ATT_STAGE;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attention_pp_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
-    hipLaunchKernelGGL((attention_pp_kernel<NW>), dim3(nitems), dim3(64 * NW), LDS, st, g);
-    return check_launch("attention_pp_kernel");
-}
-
-template <int NW, int NSTAGE, int ABL = 0>
+template <int NW, int NSTAGE, bool SPLIT>
 static int launch_attention(const AttnArgs& g, hipStream_t st) {
-    constexpr int QB = 32 * NW;
-    const int nitems = g.H * ((g.Sq + QB - 1) / QB);
     constexpr int LDS = NSTAGE * ATT_STAGE;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)attention_kernel<NW, NSTAGE, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)attention_kernel<NW, NSTAGE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
-    hipLaunchKernelGGL((attention_kernel<NW, NSTAGE, ABL>), dim3(nitems), dim3(64 * NW), LDS, st, g);
+    const int nblocks = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL((attention_kernel<NW, NSTAGE, SPLIT>), dim3(nblocks), dim3(64 * NW), LDS, st, g);
     return check_launch("attention_kernel");
+}
+
+// Round-aware schedule: items that fill whole rounds of the chip's workgroup slots run as they are;
+// the REMAINDER (which would otherwise occupy a full round at partial occupancy - 816 items on 256
+// CUs = 3.19 rounds -> 4) is cut along KV into `nsplit` ranges so that it spreads over all CUs, and
+// merged by a tiny combine kernel.
+template <int NW, int NSTAGE>
+static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, hipStream_t st) {
+    constexpr int QB = 32 * NW;
+    const int nitems = g.H * ((g.Sq + QB - 1) / QB);
+    const int ntiles = (g.Skv + KV_T - 1) / KV_T;
+    int full = (nitems / slots) * slots, left = nitems - full, best = 1;
+    if (left > 0 && ws != nullptr) {
+        float best_cost = (float)((left + slots - 1) / slots);
+        for (int S = 2; S <= 8; ++S) {
+            if (ntiles / S < 4) break;
+            if ((size_t)left * S * QB * 130 * sizeof(float) > ws_bytes) break;
+            const float cost = (float)((left * S + slots - 1) / slots) / (float)S + 0.02f;
+            if (cost < best_cost - 1e-6f) { best_cost = cost; best = S; }
+        }
+    }
+    g.ws = (float*)ws;
+    g.nsplit = 1;
+    int rc = 0;
+    if (best == 1) {
+        g.item_offset = 0; g.nitems_launch = nitems;
+        return launch_attention<NW, NSTAGE, false>(g, st);
+    }
+    if (full > 0) {
+        g.item_offset = 0; g.nitems_launch = full;
+        if ((rc = launch_attention<NW, NSTAGE, false>(g, st))) return rc;
+    }
+    g.item_offset = full; g.nitems_launch = left; g.nsplit = best;
+    if ((rc = launch_attention<NW, NSTAGE, true>(g, st))) return rc;
+    hipLaunchKernelGGL((attention_combine_kernel<QB>), dim3(left * (QB / 16)), dim3(256), 0, st, g);
+    return check_launch("attention_combine_kernel");
 }
 
 }  // namespace rgn
@@ -727,8 +368,13 @@ using namespace rgn;
 
 extern "C" {
 
+size_t rgn_attention_workspace_bytes(int Sq, int H) {
+    (void)Sq; (void)H;
+    return (size_t)128 << 20;        // 128 MiB covers every (remainder x split) choice attention_schedule makes
+}
+
 int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O, int ldo,
-                  int Sq, int Skv, int H, float scale, void* stream) {
+                  int Sq, int Skv, int H, float scale, void* workspace, size_t workspace_bytes, void* stream) {
     if (Sq == 0) return 0;
     if (!Q || !k_slab || !vt_slab || !O || Sq < 0 || Skv <= 0 || H <= 0 || (skv_pad % 64) || skv_pad < Skv ||
         (ldq % 8) || (ldo % 8))
@@ -737,28 +383,15 @@ int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_sla
     g.Q = (const uint16_t*)Q; g.K = (const uint16_t*)k_slab; g.Vt = (const uint16_t*)vt_slab; g.O = (uint16_t*)O;
     g.ldq = ldq; g.ldo = ldo; g.skv_pad = skv_pad; g.Sq = Sq; g.Skv = Skv; g.H = H;
     g.scale_log2e = scale * 1.4426950408889634f;
+    g.item_offset = 0; g.nitems_launch = 0; g.nsplit = 1; g.ws = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    // 8-wave workgroups (256 query rows share each K/V tile) once they fill the chip; 4-wave otherwise
-    const int items8 = H * ((Sq + 255) / 256);
-    int variant = (items8 >= 256) ? 83 : 42;
+    // 8-wave workgroups (256 query rows share each K/V tile, 1 per CU) unless the query set is tiny
+    int variant = (H * ((Sq + 255) / 256) >= 96) ? 8 : 4;
     const char* v = getenv("RGN_ATTN_VARIANT");
-    if (v && v[0] >= '0' && v[0] <= '9') variant = atoi(v);
-    switch (variant) {
-        case 42: return launch_attention<4, 2>(g, st);
-        case 43: return launch_attention<4, 3>(g, st);
-        case 82: return launch_attention<8, 2>(g, st);
-        case 83: return launch_attention<8, 3>(g, st);
-        case 84: return launch_attention<8, 4>(g, st);
-        case 8: return launch_attention_pipe<8>(g, st);
-        case 9: return launch_attention_pp<8>(g, st);
-        case 821: return launch_attention<8, 2, 1>(g, st);
-        case 822: return launch_attention<8, 2, 2>(g, st);
-        case 823: return launch_attention<8, 2, 3>(g, st);
-        case 824: return launch_attention<8, 2, 4>(g, st);
-        case 825: return launch_attention<8, 2, 5>(g, st);
-        case 4: return launch_attention_pipe<4>(g, st);
-        default: return fail(RGN_E_BADARG, "attention: unknown RGN_ATTN_VARIANT");
-    }
+    if (v && (v[0] == '4' || v[0] == '8')) variant = v[0] - '0';
+    if (v && v[1] == 'n') { workspace = nullptr; workspace_bytes = 0; }        // "8n" / "4n": no KV split
+    if (variant == 8) return attention_schedule<8, 3>(g, 256, workspace, workspace_bytes, st);
+    return attention_schedule<4, 2>(g, 512, workspace, workspace_bytes, st);
 }
 
 }  // extern "C"

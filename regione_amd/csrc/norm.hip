@@ -159,6 +159,13 @@ __global__ __launch_bounds__(256) void v_transpose_store_kernel(const uint16_t* 
     }
 }
 
+__global__ void silu_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = bf2f(x[i]);
+        y[i] = f2bf(v / (1.0f + expf(-v)));
+    }
+}
+
 }  // namespace rgn
 
 using namespace rgn;
@@ -175,6 +182,15 @@ int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, fl
                        (uint16_t*)out, ldo, d, eps, split_row, (const uint16_t*)shift0, (const uint16_t*)scale0,
                        (const uint16_t*)shift1, (const uint16_t*)scale1);
     return check_launch("ln_modulate_kernel");
+}
+
+int rgn_silu_bf16(const void* x, void* y, size_t n, void* stream) {
+    if (n == 0) return 0;
+    if (!x || !y) return fail(RGN_E_BADARG, "silu: null pointer");
+    size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(silu_bf16_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, (uint16_t*)y, n);
+    return check_launch("silu_bf16_kernel");
 }
 
 int rgn_qk_norm_rope_store(void* qkv, int ld, int k_col, int v_col, int q_col, int M, int H, int split_row,

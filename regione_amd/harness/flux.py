@@ -418,6 +418,35 @@ class FluxTransformer2DModel:
         t, g, p = mlp("timestep_embedder", te), mlp("guidance_embedder", ge), mlp("text_embedder", pooled)
         return (t + g) + p        # two bf16 adds, same order as the module (tiny [1, d] tensors)
 
+    # -- all-step modulation table ----------------------------------------------------------------------
+    def precompute_modulations(self, timesteps_div1000: List[torch.Tensor], guidance: torch.Tensor, pooled: torch.Tensor):
+        """temb depends only on (timestep, guidance, pooled prompt), all known before the denoise loop:
+        compute linear(silu(temb)) of every block for EVERY step in one GEMM whose M is the number of
+        steps - the 6.5 GB of AdaLN weights stream from HBM once per edit instead of once per computed
+        step.  `forward` looks rows up by the bf16 timestep value and falls back to the per-step GEMV."""
+        d = self.cfg_model.d
+        gd = guidance.to(torch.bfloat16) * 1000
+        keys, rows = [], []
+        for ts in timesteps_div1000:
+            tsb = ts.to(torch.bfloat16) * 1000
+            k = float(tsb[0])
+            if k in keys:
+                continue
+            keys.append(k)
+            rows.append(self.time_text_embed(tsb, gd, pooled))
+        temb = torch.cat(rows, 0).contiguous()                       # [S, d] bf16
+        table = torch.empty(temb.shape[0], self.mod_total, dtype=torch.bfloat16, device=self.device)
+        ops.gemm(ops.silu(temb), self.mod_w, self.mod_b, table)
+        self._mod_table = dict(keys={k: i for i, k in enumerate(keys)}, table=table, guidance=float(gd[0]),
+                               pooled_ptr=pooled.data_ptr())
+
+    def _lookup_modulation(self, ts, gd, pooled) -> Optional[Modulation]:
+        mt = getattr(self, "_mod_table", None)
+        if mt is None or mt["pooled_ptr"] != pooled.data_ptr() or mt["guidance"] != float(gd[0]):
+            return None
+        i = mt["keys"].get(float(ts[0]))
+        return None if i is None else Modulation(mt["table"][i:i + 1], self.cfg_model.d)
+
     # -- vanilla forward ------------------------------------------------------------------------------
     def forward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None, timestep=None,
                 img_ids=None, txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True):
@@ -440,8 +469,10 @@ class FluxTransformer2DModel:
         ops.gemm(encoder_hidden_states[0], self.context_embedder_weight, self.context_embedder_bias, ws.x[:T])
         ts = timestep.to(torch.bfloat16) * 1000                       # inplace.py:471
         gd = guidance.to(torch.bfloat16) * 1000
-        temb = self.time_text_embed(ts, gd, pooled)
-        mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
+        mods = self._lookup_modulation(ts, gd, pooled)
+        if mods is None:
+            temb = self.time_text_embed(ts, gd, pooled)
+            mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
         ctx = FwdCtx(ws, T, M, mods)
         for block in self.transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
@@ -514,6 +545,9 @@ class FluxKontextPipeline:
         timesteps = self.scheduler.timesteps
         guidance = torch.full([1], guidance_scale, dtype=torch.float32)
         self.scheduler.set_begin_index(0)
+        if hasattr(self.transformer, "precompute_modulations"):
+            self.transformer.precompute_modulations([t.expand(1).to(latents.dtype) / 1000 for t in timesteps], guidance,
+                                                    pooled_prompt_embeds)
         for i, t in enumerate(timesteps):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)

@@ -181,6 +181,13 @@ def gemv(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], silu_in
     return out
 
 
+def silu(x: torch.Tensor) -> torch.Tensor:
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().rgn_silu_bf16(_p(x), _p(y), x.numel(), _stream()), "rgn_silu_bf16")
+    return y
+
+
 def ln_modulate(x: torch.Tensor, out: torch.Tensor, shift1, scale1, split_row: int = 0, shift0=None, scale0=None,
                 eps: float = 1e-6) -> torch.Tensor:
     M, d = x.shape
@@ -203,14 +210,28 @@ def qk_norm_rope_store(qkv: torch.Tensor, k_col: int, v_col: int, q_col: int, H:
     _lib.check(rc, "rgn_qk_norm_rope_store")
 
 
+_attn_ws = {}
+
+
+def attention_workspace(device) -> torch.Tensor:
+    """fp32 scratch for the round-aware attention schedule (allocated once per device)."""
+    key = str(device)
+    if key not in _attn_ws:
+        n = _lib.lib().rgn_attention_workspace_bytes(0, 0)
+        _attn_ws[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
+    return _attn_ws[key]
+
+
 def attention(q: torch.Tensor, k_slab: torch.Tensor, vt_slab: torch.Tensor, out: torch.Tensor, skv: int, H: int,
-              scale: Optional[float] = None) -> torch.Tensor:
+              scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q / out: [Sq, H*128] views (row stride free, may alias)."""
     Sq = q.shape[0]
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
+    if workspace is None:
+        workspace = attention_workspace(q.device)
     rc = _lib.lib().rgn_attention(_p(q), q.stride(0), _p(k_slab), _p(vt_slab), k_slab.shape[0], _p(out), out.stride(0),
-                                  Sq, skv, H, float(scale), _stream())
+                                  Sq, skv, H, float(scale), _p(workspace), workspace.numel() * 4, _stream())
     _lib.check(rc, "rgn_attention")
     return out
 

@@ -63,7 +63,7 @@ def bench_gemv():
 
 
 VARIANTS = os.environ.get("GEMM_VARIANTS", "auto").split(",")
-AVARIANTS = os.environ.get("ATTN_VARIANTS", "auto").split(",")
+AVARIANTS = os.environ.get("ATTN_VARIANTS", "auto").split(",")   # e.g. 8,8n,4,4n (n = no KV split)
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "gemv"]
     if "gemm" in which: bench_gemm()
