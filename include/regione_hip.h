@@ -104,7 +104,12 @@ int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio,
 #define RGN_EPI_GATE_RESID 2
 int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc,
                   int M, int N, int K, int epilogue, int gelu_from_col, const void* gate,
-                  const void* resid, const int64_t* out_rows, void* stream);
+                  const void* resid, const int64_t* out_rows, void* workspace, size_t workspace_bytes,
+                  void* stream);
+/* `workspace` (optional, fp32 scratch, rgn_gemm_workspace_bytes()) enables the round-aware schedule:
+ * output tiles that do not fill a whole round of the chip's workgroup slots are cut along K, spread
+ * over all CUs and finished by a reduce pass.  NULL = plain single launch. */
+size_t rgn_gemm_workspace_bytes(void);
 
 /* Two independent problems with the same N, K and epilogue in ONE launch (the text and image
  * streams of a double block: different A / W / bias / C / gate / resid).  The small problem's tiles
@@ -112,7 +117,8 @@ int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bi
 int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
                        const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1,
                        const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1,
-                       int N, int K, int epilogue, int gelu_from_col, void* stream);
+                       int N, int K, int epilogue, int gelu_from_col, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* Skinny GEMV for the AdaLN modulation / timestep embedders:
  *   y[b,n] = bf16( sum_k W[n,k] * act(x[b,k]) + bias[n] ),  act = silu (rounded to bf16) if silu_input.

@@ -32,10 +32,11 @@ SIGNATURES = {
                        _c_int, _c_void_p],
     "rgn_avd_apply": [_c_void_p, _c_int, _c_void_p, _c_float, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
     "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
-                      _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+                      _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_gemm_workspace_bytes": [],
     "rgn_gemm_bf16_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                            _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
-                           _c_int, _c_int, _c_int, _c_int, _c_void_p],
+                           _c_int, _c_int, _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_void_p],
     "rgn_silu_bf16": [_c_void_p, _c_void_p, C.c_size_t, _c_void_p],
@@ -48,7 +49,8 @@ SIGNATURES = {
                       _c_float, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_attention_workspace_bytes": [_c_int, _c_int],
 }
-_RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_attention_workspace_bytes": C.c_size_t}
+_RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_attention_workspace_bytes": C.c_size_t,
+            "rgn_gemm_workspace_bytes": C.c_size_t}
 
 _lib = None
 

@@ -19,6 +19,7 @@
 // the result is rounded ONCE to the cache dtype (no fp16 round trip, quirk A-3).
 #include "common.h"
 #include <stdlib.h>
+#include <math.h>
 
 namespace rgn {
 
@@ -42,23 +43,38 @@ struct GemmArgs {
 constexpr int BK = 64;
 
 __device__ __forceinline__ float gelu_tanh(float x) {
-    // torch GELU(approximate='tanh') opmath: 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
+    // torch GELU(approximate='tanh'): 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x+0.044715 x^3)
+    //   = x * sigmoid(2u) = x / (1 + 2^(-2u*log2(e)))      (one v_exp_f32 + one v_rcp_f32)
     const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-    float inner = kBeta * (x + kKappa * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(inner));
+    const float u = kBeta * (x + kKappa * x * x * x);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
+}
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    bf2_t r = __builtin_convertvector(f32x2{a, b}, bf2_t);     // v_cvt_pk_bf16_f32 (RNE)
+    return *(uint32_t*)&r;
 }
 
 struct GemmGroup {
     GemmArgs p[2];      // up to two problems per launch (e.g. text + image stream of a double block)
     int nt0;            // tiles of problem 0; tiles >= nt0 belong to problem 1
     int nt;             // total tiles
+    // round-aware launch: this launch covers tiles [tile_offset, tile_offset + nt_launch).
+    // MODE 1 cuts each tile's K range into nsplit pieces (fp32 partial fragments -> ws);
+    // MODE 2 sums the partials of each tile and runs the normal epilogue.
+    int tile_offset, nt_launch, nsplit;
+    float* ws;
 };
+
+constexpr int MODE_FULL = 0, MODE_PARTIAL = 1, MODE_REDUCE = 2;
 
 // Tile configurations:
 //   <128,128,2,2>: 4 waves, wave tile 64x64, 64 KiB LDS, 2 blocks/CU  - small / ragged problems
 //   <256,256,2,4>: 8 waves, wave tile 128x64, 128 KiB LDS, 1 block/CU - large problems (half the
 //                  global->LDS traffic and 25 % less LDS read traffic per FLOP)
-template <int EPI, int BM, int BN, int WM, int WN>
+template <int EPI, int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf16_kernel(const GemmGroup gg) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16x16 MFMA tiles per wave
@@ -72,11 +88,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
     const int wm = wave / WN, wn = wave % WN;
 
     // ---- XCD-aware bijective tile map (T1) over both problems + grouped ordering ------------------
-    int t;
+    int t, split = 0, unit;
     {
+        const int nb = (MODE == MODE_PARTIAL) ? gg.nt_launch * gg.nsplit : gg.nt_launch;
         const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
-        const int q = gg.nt >> 3, r = gg.nt & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int q = nb >> 3, r = nb & 7;
+        unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        t = unit;
+        if (MODE == MODE_PARTIAL) { split = t % gg.nsplit; t /= gg.nsplit; }
+        unit = t;                       // launch-local tile index (workspace slot)
+        t += gg.tile_offset;
     }
     const int pi = (t >= gg.nt0) ? 1 : 0;
     const GemmArgs& g = gg.p[pi];
@@ -133,29 +154,59 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const uint8_t* sb = smem + cur * STAGE;
+    const int nk_all = g.K / BK;
+    int k_begin = 0, nk = nk_all;
+    if (MODE == MODE_PARTIAL) {
+        const int per = (nk_all + gg.nsplit - 1) / gg.nsplit;
+        k_begin = split * per;
+        nk = max(0, min(per, nk_all - k_begin));
+    }
+    if (MODE != MODE_REDUCE && nk > 0) {
+        stage(k_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(k_begin + kt + 1, cur ^ 1);
+            const uint8_t* sb = smem + cur * STAGE;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf8_t af[TM], bfr[TN];
+            for (int kk = 0; kk < 2; ++kk) {
+                bf8_t af[TM], bfr[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
+                for (int j = 0; j < TN; ++j) bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const bf8_t*)(sb + a_off[kk] + i * 2048);
+                for (int i = 0; i < TM; ++i) af[i] = *(const bf8_t*)(sb + a_off[kk] + i * 2048);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C^T fragment
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (MODE == MODE_PARTIAL) {
+        // lane-linear fp32 fragment dump: [unit][split][fragment (i,j)][thread] float4 - fully coalesced
+        float4* w = (float4*)gg.ws + ((size_t)unit * gg.nsplit + split) * (size_t)(TM * TN * NT) + tid;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                w[(size_t)(i * TN + j) * NT] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        return;
+    }
+    if (MODE == MODE_REDUCE) {
+        const float4* w = (const float4*)gg.ws + (size_t)unit * gg.nsplit * (size_t)(TM * TN * NT) + tid;
+        for (int sp = 0; sp < gg.nsplit; ++sp) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    const float4 v = w[(size_t)(sp * TM * TN + i * TN + j) * NT];
+                    acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+                }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
 
     // ---- epilogue: per row-chunk (one wave row): acc + bias -> bf16 -> LDS -> 16-byte stores ------
@@ -173,16 +224,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
 #pragma unroll
     for (int ch = 0; ch < WM; ++ch) {
         if (wm == ch) {
-            const int ccol = lane & 15, crow = (lane >> 4) * 4;
+            // operands are fed swapped (W fragment as the MFMA row operand), so a lane's 4 accumulator
+            // registers are 4 CONSECUTIVE COLUMNS of one output row: one 8-byte LDS write per fragment
+            const int mrow = lane & 15, ncol4 = (lane >> 4) * 4;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / WN) + j * 16 + ccol;
-                const float bv = (g.bias != nullptr && n < g.N) ? bf2f(g.bias[n]) : 0.f;
+                const int nl = wn * (BN / WN) + j * 16 + ncol4;
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias != nullptr) {
+                    if (n0 + nl + 4 <= g.N) {
+                        const uint2 b2 = *(const uint2*)(g.bias + n0 + nl);
+                        bv[0] = bf2f(b2.x & 0xffff); bv[1] = bf2f(b2.x >> 16); bv[2] = bf2f(b2.y & 0xffff); bv[3] = bf2f(b2.y >> 16);
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n0 + nl + r < g.N) bv[r] = bf2f(g.bias[n0 + nl + r]);
+                    }
+                }
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ct[(i * 16 + crow + r) * CT_LD + wn * (BN / WN) + j * 16 + ccol] = f2bf(acc[i][j][r] + bv);
+                for (int i = 0; i < TM; ++i) {
+                    const uint2 w = make_uint2(cvt_pk_bf16(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
+                                               cvt_pk_bf16(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
+                    *(uint2*)(ct + (i * 16 + mrow) * CT_LD + nl) = w;
+                }
             }
         }
         __syncthreads();
@@ -262,21 +324,27 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const uint16_t* __restri
 
 using namespace rgn;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
     constexpr int NT = 64 * WM * WN;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
+    const int nb = (MODE == MODE_PARTIAL) ? gg.nt_launch * gg.nsplit : gg.nt_launch;
+    if (nb == 0) return 0;
+    if (MODE == MODE_PARTIAL) {       // partial fragments carry no epilogue
+        hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg);
+        return check_launch("gemm_bf16_kernel(partial)");
+    }
     switch (epilogue) {
-        case RGN_EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN>), dim3(gg.nt), dim3(NT), LDS, st, gg); break;
-        case RGN_EPI_GELU: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN>), dim3(gg.nt), dim3(NT), LDS, st, gg); break;
-        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN>), dim3(gg.nt), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_GELU: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
         default: return fail(RGN_E_BADARG, "gemm: unknown epilogue");
     }
     return check_launch("gemm_bf16_kernel");
@@ -295,14 +363,58 @@ static int check_problem(const void* A, int lda, const void* W, int ldw, const v
 
 static inline int tiles(int M, int N, int b) { return ((M + b - 1) / b) * ((N + b - 1) / b); }
 
-static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, hipStream_t st) {
+// Round-aware schedule (same idea as attention_schedule): tiles that fill whole rounds of the chip's
+// workgroup slots run as they are; the remainder is cut along K into nsplit pieces spread over all
+// CUs (fp32 fragment partials in `ws`) and finished by a reduce pass that owns the epilogue.
+template <int BM, int BN, int WM, int WN>
+static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int nt = gg.nt;
+    const int K = gg.p[0].K, nk = K / BK;
+    const int full = (nt / slots) * slots, left = nt - full;
+    int best = 1;
+    if (left > 0 && ws != nullptr) {
+        // cost model in microseconds (measured on MI355X: ~4.3 TFLOP/s per CU in the main loop, ~5 us
+        // fixed cost per sub-block, ~10 us of drain per extra launch, partials at ~4 TB/s)
+        const size_t tile_bytes = (size_t)BM * BN * 4;
+        const float t_tile = 2.0f * BM * BN * (float)K / 4.3e12f * 1e6f;
+        const float base = (float)((left + slots - 1) / slots) * t_tile;
+        const float total = (float)((nt + slots - 1) / slots) * t_tile;
+        float best_cost = base;
+        for (int S = 2; S <= 6; ++S) {
+            if (nk / S < 8) break;
+            if ((size_t)left * S * tile_bytes > ws_bytes) break;
+            const float traffic = (float)((size_t)left * S * tile_bytes * 2) / 4.0e12f * 1e6f;
+            const float cost = (float)((left * S + slots - 1) / slots) * (t_tile / (float)S + 5.0f) + traffic + 10.0f;
+            if (cost < best_cost) { best_cost = cost; best = S; }
+        }
+        if (base - best_cost < fmaxf(30.0f, 0.05f * total)) best = 1;      // not worth two extra launches
+    }
+    const char* v = getenv("RGN_GEMM_SPLIT");
+    if (v && v[0] == '0') best = 1;
+    gg.ws = (float*)ws;
+    gg.nsplit = 1;
+    int rc;
+    if (best == 1) {
+        gg.tile_offset = 0; gg.nt_launch = nt;
+        return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
+    }
+    if (full > 0) {
+        gg.tile_offset = 0; gg.nt_launch = full;
+        if ((rc = launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st))) return rc;
+    }
+    gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = best;
+    if ((rc = launch_gemm<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, st))) return rc;
+    return launch_gemm<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, st);
+}
+
+static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_t ws_bytes, hipStream_t st) {
     // tile choice by estimated throughput = asymptotic rate x wave-quantisation efficiency:
     // 256x256 (1 block/CU, 256 slots, ~1150 TF) vs 128x128 (2 blocks/CU, 512 slots, ~1000 TF)
     int big = 0, small_ = 0;
     for (int i = 0; i < nprob; ++i) { big += tiles(gg.p[i].M, gg.p[i].N, 256); small_ += tiles(gg.p[i].M, gg.p[i].N, 128); }
     const float eff_big = (float)big / (float)(((big + 255) / 256) * 256);
     const float eff_small = (float)small_ / (float)(((small_ + 511) / 512) * 512);
-    bool use_big = 1150.f * eff_big > 1000.f * eff_small;
+    bool use_big = ws ? (big >= 200) : (1150.f * eff_big > 1000.f * eff_small);   // with the split remainder, quantisation no longer decides
     const char* v = getenv("RGN_GEMM_VARIANT");
     if (v && v[0] == '1') use_big = false;
     if (v && v[0] == '2') use_big = true;
@@ -310,7 +422,8 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, hipStream_t st)
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
     if (gg.nt == 0) return 0;
-    return use_big ? launch_gemm<256, 256, 2, 4>(gg, epilogue, st) : launch_gemm<128, 128, 2, 2>(gg, epilogue, st);
+    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, ws, ws_bytes, st)
+                   : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, ws, ws_bytes, st);
 }
 
 static void fill(GemmArgs& g, const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M,
@@ -324,23 +437,23 @@ extern "C" {
 
 int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
                   int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
-                  const int64_t* out_rows, void* stream) {
+                  const int64_t* out_rows, void* workspace, size_t workspace_bytes, void* stream) {
     if (M == 0) return 0;
     int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, resid);
     if (rc) return rc;
     GemmGroup gg;
     fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, gate, resid, out_rows);
     gg.p[1] = gg.p[0];
-    return gemm_dispatch(gg, 1, epilogue, (hipStream_t)stream);
+    return gemm_dispatch(gg, 1, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
                        const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1,
                        const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1, int N,
-                       int K, int epilogue, int gelu_from_col, void* stream) {
+                       int K, int epilogue, int gelu_from_col, void* workspace, size_t workspace_bytes, void* stream) {
     if (M0 == 0 && M1 == 0) return 0;
-    if (M0 == 0) return rgn_gemm_bf16(A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, epilogue, gelu_from_col, gate1, resid1, nullptr, stream);
-    if (M1 == 0) return rgn_gemm_bf16(A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, epilogue, gelu_from_col, gate0, resid0, nullptr, stream);
+    if (M0 == 0) return rgn_gemm_bf16(A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, epilogue, gelu_from_col, gate1, resid1, nullptr, workspace, workspace_bytes, stream);
+    if (M1 == 0) return rgn_gemm_bf16(A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, epilogue, gelu_from_col, gate0, resid0, nullptr, workspace, workspace_bytes, stream);
     int rc = check_problem(A0, lda0, W0, K, C0, ldc0, M0, N, K, epilogue, gate0, resid0);
     if (rc) return rc;
     rc = check_problem(A1, lda1, W1, K, C1, ldc1, M1, N, K, epilogue, gate1, resid1);
@@ -348,8 +461,10 @@ int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bia
     GemmGroup gg;
     fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, gelu_from_col, gate0, resid0, nullptr);
     fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, gelu_from_col, gate1, resid1, nullptr);
-    return gemm_dispatch(gg, 2, epilogue, (hipStream_t)stream);
+    return gemm_dispatch(gg, 2, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+size_t rgn_gemm_workspace_bytes(void) { return (size_t)256 << 20; }
 
 int rgn_gemv_bf16(const void* x, int ldx, const void* W, const void* bias, void* y, int ldy, int B, int N, int K,
                   int silu_input, void* stream) {

@@ -137,6 +137,17 @@ def avd_apply(cache: torch.Tensor, ratio: float, ids: Optional[torch.Tensor] = N
 # ---------------------------------------------------------------------------------------------
 # MMDiT block kernels
 # ---------------------------------------------------------------------------------------------
+_gemm_ws = {}
+
+
+def gemm_workspace(device) -> torch.Tensor:
+    """fp32 scratch for the round-aware GEMM schedule (allocated once per device)."""
+    key = str(device)
+    if key not in _gemm_ws:
+        _gemm_ws[key] = torch.empty(_lib.lib().rgn_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device)
+    return _gemm_ws[key]
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, epilogue: int = EPI_BIAS,
          gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
          out_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -147,8 +158,10 @@ def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: to
     assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and W.shape[1] == K and out.shape[1] == N
     if resid is not None:
         assert resid.stride(0) == out.stride(0) and resid.stride(1) == 1
+    ws = gemm_workspace(A.device)
     rc = _lib.lib().rgn_gemm_bf16(_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
-                                  epilogue, gelu_from_col, _p(gate), _p(resid), _p(out_rows), _stream())
+                                  epilogue, gelu_from_col, _p(gate), _p(resid), _p(out_rows), _p(ws), ws.numel() * 4,
+                                  _stream())
     _lib.check(rc, "rgn_gemm_bf16")
     return out
 
@@ -161,10 +174,11 @@ def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, g
     assert A0.shape[1] == K and A1.shape[1] == K and out0.shape[1] == N and out1.shape[1] == N
     for t in (A0, A1, out0, out1):
         assert t.stride(1) == 1 and t.dtype == torch.bfloat16
+    ws = gemm_workspace(A0.device)
     rc = _lib.lib().rgn_gemm_bf16_pair(_p(A0), A0.stride(0), _p(W0), _p(b0), _p(out0), out0.stride(0), A0.shape[0],
                                        _p(gate0), _p(resid0), _p(A1), A1.stride(0), _p(W1), _p(b1), _p(out1),
                                        out1.stride(0), A1.shape[0], _p(gate1), _p(resid1), N, K, epilogue,
-                                       gelu_from_col, _stream())
+                                       gelu_from_col, _p(ws), ws.numel() * 4, _stream())
     _lib.check(rc, "rgn_gemm_bf16_pair")
 
 
