@@ -242,11 +242,8 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("nccl", device_id=device)
+    from regione_amd import dist as D
+    dist = D.init("nccl", device) if world > 1 else None
 
     from regione_amd import RegionEHelper, synth, ops
     from oracle import regione_oracle as O            # checker / cpu_baseline leg only
@@ -279,30 +276,18 @@ def main():
         return pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=args.size, width=args.size,
                     latents=lat, guidance_scale=2.5, return_dict=False, trace=trace)[0]
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         out = edit()
     timer = KernelTimer()
     timer.wrap(ops)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = edit()
-        if dist is not None:
-            gathered = [torch.empty_like(out) for _ in range(world)]
-            dist.all_gather(gathered, out)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+
+    def job():
+        for _ in range(args.steps):
+            o = edit()
+            # every rank ends with every image's final latents (512 KB each): the only data collective
+            D.gather_latents([o], [rank], world, dist)
+    elapsed = D.timed(job, torch.cuda.synchronize, dist)       # barrier + sync both sides, MAX over ranks
     timer.unwrap()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
 
     # characterise the run (untimed): step kinds, K_e
     trace = {}

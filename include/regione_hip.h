@@ -90,6 +90,18 @@ int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio,
                   int K, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * a11  classifier-free-guidance combine of the cond / uncond velocities, rows of 64 channels:
+ *   mode 0  FLUX true-CFG (inplace.py:364)                      out = neg + s*(pos-neg)
+ *   mode 1  Step1X norm-rescaled (Step1XEdit/inplace.py:401-410) out = neg + s*(pos-neg)/f(||pos-neg||),
+ *           f(n) = n > 1 ? n^power : (n < 1 ? 1 : n)
+ *   mode 2  Qwen norm-preserving (QwenImageEdit/inplace.py:401-405)
+ *           c = neg + s*(pos-neg);  out = c * (||pos|| / ||c||)
+ * Every intermediate is rounded to the tensor dtype like the eager op sequence.
+ */
+int rgn_cfg_combine(const void* pos, const void* neg, void* out, int dtype, float scale, int mode, float power,
+                    int K, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * bf16 MFMA GEMM  C = epilogue(A[M,K] @ W[N,K]^T + bias)  (fp32 accumulate).
  * Replaces torch nn.Linear calls of the block bodies [EXT diffusers] and, with `out_rows`,
  * the Triton index-scatter GEMM _partially_linear (fused_kernels.py:9-101).

@@ -521,10 +521,14 @@ def transformer_forward(w, cfg: FluxCfg, st: RegionState, caches: List[KVCache],
 # a11  denoise loop
 # --------------------------------------------------------------------------------------
 def denoise(model_fn, st: RegionState, latents, image_latents, latent_ids, txt_length, h_tok, w_tok,
-            family="flux", regione=True, trace: Optional[dict] = None):
+            family="flux", regione=True, trace: Optional[dict] = None, neg_model_fn=None, true_cfg_scale: float = 1.0):
     """inplace.py:229-244,287-392 (true_cfg_scale = 1: FLUX-Kontext's normal, guidance-distilled use).
 
     model_fn(latent_model_input, t (0-dim fp32 timestep), img_ids) -> velocity for all input rows.
+    neg_model_fn + true_cfg_scale > 1: the sequential second (unconditional) forward of inplace.py:349-364.
+    In the reference both forwards go through the SAME processors, i.e. one K/V cache is shared by the
+    two branches (quirk A-4); give the two closures the same `caches` list to reproduce that, or
+    separate lists for the per-branch caches Qwen / Step1X-v1p2 use.
     latent_ids: FULL id table [L + L_c, 3].  With regione=False this is the vanilla loop
     (every step full-token, plain Euler), used for the speed-up / PSNR-vs-vanilla figures."""
     n = st.inference_step
@@ -552,6 +556,9 @@ def denoise(model_fn, st: RegionState, latents, image_latents, latent_ids, txt_l
             if st.is_full_input_step():                                               # :331-332
                 x = torch.cat([latents, image_latents], dim=1)
             noise_pred = model_fn(x, timesteps[i], ids)[:, :latents.size(1)]          # :336-347
+            if neg_model_fn is not None and true_cfg_scale > 1:                       # true CFG, :349-364
+                neg = neg_model_fn(x, timesteps[i], ids)[:, :latents.size(1)]
+                noise_pred = neg + true_cfg_scale * (noise_pred - neg)
             cache = noise_pred                                                        # :365
         if trace is not None:
             trace.setdefault("kind", []).append("C" if hit else ("F" if st.is_full_input_step() else "R"))

@@ -36,9 +36,15 @@ gamma = torch.tensor([0.8352, 0.9986, 1.0090, 1.0097, 1.0161, 1.0152, 1.0160, 1.
 
 
 def warp_modules(pipeline, **args):
-    """inplace.py:53-62.  The manager is attached to the pipeline instead of being a module global."""
+    """inplace.py:53-62.  The manager is attached to the pipeline instead of being a module global.
+    Extra (non-reference) key `strict_reference`: share ONE K/V cache between the cond / uncond
+    forwards of FLUX true-CFG exactly like the reference does (quirk A-4); default False = one cache
+    per branch, the fix Qwen / Step1X-v1p2 apply (QwenImageEdit/inplace.py:731-734)."""
+    args = dict(args)
+    strict = bool(args.pop("strict_reference", False))
     manager = FluxKontextManager()
     manager.set_parameters(args)
+    manager.strict_reference = strict
     pipeline._regione_manager = manager
     pipeline._regione_vanilla_class = pipeline.__class__
     pipeline.__class__ = RegionEFluxKontextPipeline
@@ -105,7 +111,8 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, guidance_scale=2.5, latents=None, generator=None, output_type="latent",
-                 return_dict=True, callback_on_step_end=None, trace: Optional[dict] = None):
+                 return_dict=True, callback_on_step_end=None, true_cfg_scale: float = 1.0,
+                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, trace: Optional[dict] = None):
         MANAGER: FluxKontextManager = self._regione_manager
         assert num_inference_steps == MANAGER.inference_step, "num_inference_steps should be equal to 28"
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
@@ -114,10 +121,10 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
         guidance = torch.full([1], guidance_scale, dtype=torch.float32)
         MANAGER.refresh(latents, image_latents, latent_ids, text_ids, 2, self.vae_scale_factor, height, width)
         avd, cache = AvdState(), None
+        do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None
         self.scheduler.set_begin_index(0)
-        if hasattr(self.transformer, "precompute_modulations"):
-            self.transformer.precompute_modulations([t.expand(1).to(latents.dtype) / 1000 for t in timesteps], guidance,
-                                                    pooled_prompt_embeds)
+        self._precompute(timesteps, guidance, latents.dtype, pooled_prompt_embeds,
+                         negative_pooled_prompt_embeds if do_true_cfg else None)
         for i, t in enumerate(timesteps):
             assert i == MANAGER.current_step
             should_cache, ratio = avd_decide(MANAGER, avd, i, timesteps)
@@ -134,8 +141,16 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                 noise_pred = self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000,
                                               guidance=guidance, pooled_projections=pooled_prompt_embeds,
                                               encoder_hidden_states=prompt_embeds, txt_ids=text_ids,
-                                              img_ids=latent_ids, return_dict=False)[0]
+                                              img_ids=latent_ids, joint_attention_kwargs={"tag": "cond"},
+                                              return_dict=False)[0]
                 noise_pred = noise_pred[:, : latents.size(1)]
+                if do_true_cfg:                                                 # inplace.py:349-364
+                    neg = self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000,
+                                           guidance=guidance, pooled_projections=negative_pooled_prompt_embeds,
+                                           encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,
+                                           img_ids=latent_ids, joint_attention_kwargs={"tag": "uncond"},
+                                           return_dict=False)[0][:, : latents.size(1)]
+                    noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
                 cache = noise_pred                                              # inplace.py:365
             if trace is not None:
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))
@@ -168,7 +183,7 @@ def RegionEFluxTransformer2DModelforward(self, hidden_states, encoder_hidden_sta
             MANAGER.rope_q_region = tuple(ops.gather_rows(t, MANAGER.sel_rows) for t in MANAGER.image_rotary_emb)
         image_rotary_emb = MANAGER.rope_q_region         # rows of the full table at [text ; edited ids]
     return self._run(hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, image_rotary_emb,
-                     return_dict)
+                     return_dict, joint_attention_kwargs)
 
 
 class RegionEFlowMatchEulerDiscreteScheduler(H.FlowMatchEulerDiscreteScheduler):
@@ -209,30 +224,43 @@ class RegionEFlowMatchEulerDiscreteScheduler(H.FlowMatchEulerDiscreteScheduler):
 
 class RegionEFluxAttnProcessor(H.FluxAttnProcessor):
     """Region-Instruction KV-cache protocol (inplace.py:694-824).  The cache of a layer is one K slab
-    [skv_pad, d] + one V^T slab [d, skv_pad] covering [text rows ; all image rows]."""
+    [skv_pad, d] + one V^T slab [d, skv_pad] covering [text rows ; all image rows], one pair per CFG
+    branch tag (`k_cache_even/odd` of Step1XEditV1P2/inplace.py:800-888, QwenImageEdit/inplace.py:731)."""
 
     def __init__(self, single: bool, manager: Optional[FluxKontextManager] = None):
         super().__init__(single)
         self.manager = manager
-        self.k_cache = None
-        self.v_cache = None
+        self.caches = {}                 # tag -> (k_slab, vt_slab, skv)
+
+    @property
+    def k_cache(self):
+        c = next(iter(self.caches.values()), None)
+        return None if c is None else c[0]
+
+    @property
+    def v_cache(self):
+        c = next(iter(self.caches.values()), None)
+        return None if c is None else c[1]
 
     def kv_target(self, attn, ctx):
         MANAGER, ws = self.manager, ctx.ws
         phase = MANAGER.kv_phase()
         if phase == "plain":                                                      # :717-719
             return ws.k_scratch, ws.vt_scratch, None, ctx.T + ctx.M, None
+        tag = None if getattr(MANAGER, "strict_reference", False) else ctx.tag
         d = attn.heads * attn.head_dim
         if phase == "store":                                                      # :721-725
             skv = ctx.T + ctx.M
             pad = ops.padded(skv)
-            if self.k_cache is None or self.k_cache.shape[0] != pad:
-                self.k_cache = torch.zeros(pad, d, dtype=torch.bfloat16, device=ws.device)
-                self.v_cache = torch.zeros(d, pad, dtype=torch.bfloat16, device=ws.device)
-            self.skv = skv
-            return self.k_cache, self.v_cache, None, skv, None
+            c = self.caches.get(tag)
+            if c is None or c[0].shape[0] != pad:
+                c = (torch.zeros(pad, d, dtype=torch.bfloat16, device=ws.device),
+                     torch.zeros(d, pad, dtype=torch.bfloat16, device=ws.device), skv)
+            self.caches[tag] = (c[0], c[1], skv)
+            return c[0], c[1], None, skv, None
         # update: only rows [text ; T + edited_ids] are recomputed (:727-750)
-        return self.k_cache, self.v_cache, MANAGER.sel_rows, self.skv, MANAGER.image_rotary_emb
+        k, v, skv = self.caches[tag]
+        return k, v, MANAGER.sel_rows, skv, MANAGER.image_rotary_emb
 
 
 RegoionEFluxAttnProcessor2_0 = RegionEFluxAttnProcessor      # the reference's (misspelled) class name

@@ -80,6 +80,7 @@ class FluxKontextManager:
         self.sel_rows = None             # i64 [T + K_e]: cache rows a region step rewrites
         self.image_rotary_emb = None     # (cos, sin) for the FULL id table
         self.rope_q_region = None        # (cos, sin) rows of the compacted query set
+        self.strict_reference = False    # share one K/V cache between CFG branches like the reference (A-4)
 
     def set_parameters(self, args) -> None:
         assert args["warmup_step"] >= 1 and args["num_inference_steps"] == 28, \

@@ -31,6 +31,7 @@ SIGNATURES = {
     "rgn_euler_step": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_float, _c_float, _c_int,
                        _c_int, _c_void_p],
     "rgn_avd_apply": [_c_void_p, _c_int, _c_void_p, _c_float, _c_int, _c_void_p, _c_int, _c_int, _c_void_p],
+    "rgn_cfg_combine": [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_float, _c_int, _c_float, _c_int, _c_int, _c_void_p],
     "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                       _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemm_workspace_bytes": [],

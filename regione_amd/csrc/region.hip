@@ -195,6 +195,47 @@ __global__ void avd_kernel(const T* __restrict__ cache, const int64_t* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// a11 classifier-free-guidance combine, one wave per token row (D == 64), eager rounding points
+//   mode 0  FLUX true-CFG          neg + s*(pos-neg)                                inplace.py:364
+//   mode 1  Step1X norm-rescale    neg + s*(pos-neg)/f(||pos-neg||)                 Step1XEdit/inplace.py:401-410
+//           f(n) = n>1 ? n^k : (n<1 ? 1 : n)   [EXT Step1XEditPipeline.process_diff_norm]
+//   mode 2  Qwen norm-preserving   c = neg + s*(pos-neg); c * (||pos|| / ||c||)     QwenImageEdit/inplace.py:401-405
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float rnd(float x);
+template <> __device__ __forceinline__ float rnd<uint16_t>(float x) { return rbf(x); }
+template <> __device__ __forceinline__ float rnd<float>(float x) { return x; }
+template <typename T> __device__ __forceinline__ void st_from_f32(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void st_from_f32<uint16_t>(uint16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+template <> __device__ __forceinline__ void st_from_f32<float>(float* p, size_t i, float v) { p[i] = v; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_combine_kernel(const T* __restrict__ pos, const T* __restrict__ neg,
+                                                          T* __restrict__ out, float scale, int mode, float power,
+                                                          int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= K) return;
+    const size_t i = (size_t)row * 64 + lane;
+    const float p = ld_as_f32<T>(pos, i), n = ld_as_f32<T>(neg, i);
+    const float d = rnd<T>(__fsub_rn(p, n));                       // (pos - neg) in the tensor dtype
+    float sd = rnd<T>(__fmul_rn(scale, d));                        // python-float scale: fp32 opmath, one rounding
+    if (mode == 1) {
+        float nrm = rnd<T>(sqrtf(wave_sum(__fmul_rn(d, d))));      // torch.norm(diff, dim=2, keepdim=True)
+        float f = nrm;
+        if (nrm > 1.0f) f = rnd<T>(powf(nrm, power));
+        else if (nrm < 1.0f) f = 1.0f;
+        sd = rnd<T>(sd / f);
+    }
+    float c = rnd<T>(__fadd_rn(n, sd));
+    if (mode == 2) {
+        const float cn = rnd<T>(sqrtf(wave_sum(__fmul_rn(p, p))));
+        const float nn = rnd<T>(sqrtf(wave_sum(__fmul_rn(c, c))));
+        c = rnd<T>(__fmul_rn(c, rnd<T>(cn / nn)));
+    }
+    st_from_f32<T>(out, i, c);
+}
+
 static inline int grid_for(size_t n, int block) {
     size_t g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -315,6 +356,18 @@ int rgn_euler_step(const void* sample, int sample_dtype, const void* v, int v_dt
     else if (vb) hipLaunchKernelGGL((euler_kernel<float, uint16_t>), dim3(g), dim3(256), 0, st, (const float*)sample, (const uint16_t*)v, (uint16_t*)out, mask, dt, dt_direct, n, D);
     else hipLaunchKernelGGL((euler_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)sample, (const float*)v, (float*)out, mask, dt, dt_direct, n, D);
     return check_launch("euler_kernel");
+}
+
+int rgn_cfg_combine(const void* pos, const void* neg, void* out, int dtype, float scale, int mode, float power, int K,
+                    int D, void* stream) {
+    if (K == 0) return 0;
+    if (!pos || !neg || !out || K < 0 || mode < 0 || mode > 2) return fail(RGN_E_BADARG, "cfg_combine: bad argument");
+    if (D != 64) return fail(RGN_E_UNSUPPORTED, "cfg_combine: latent width must be 64");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((K + 3) / 4), b(256);
+    if (dtype == RGN_BF16) hipLaunchKernelGGL((cfg_combine_kernel<uint16_t>), g, b, 0, st, (const uint16_t*)pos, (const uint16_t*)neg, (uint16_t*)out, scale, mode, power, K);
+    else hipLaunchKernelGGL((cfg_combine_kernel<float>), g, b, 0, st, (const float*)pos, (const float*)neg, (float*)out, scale, mode, power, K);
+    return check_launch("cfg_combine_kernel");
 }
 
 int rgn_avd_apply(const void* cache, int dtype, const int64_t* ids, float ratio, int round_ratio, void* out, int K,

@@ -182,8 +182,8 @@ class Modulation:
 class FwdCtx:
     """Per-forward context handed to the processors alongside the reference's arguments."""
 
-    def __init__(self, ws: Workspace, T: int, M: int, mods: Modulation):
-        self.ws, self.T, self.M, self.mods = ws, T, M, mods
+    def __init__(self, ws: Workspace, T: int, M: int, mods: Modulation, tag=None):
+        self.ws, self.T, self.M, self.mods, self.tag = ws, T, M, mods, tag
 
 
 # ---------------------------------------------------------------------------------------------
@@ -437,12 +437,17 @@ class FluxTransformer2DModel:
         temb = torch.cat(rows, 0).contiguous()                       # [S, d] bf16
         table = torch.empty(temb.shape[0], self.mod_total, dtype=torch.bfloat16, device=self.device)
         ops.gemm(ops.silu(temb), self.mod_w, self.mod_b, table)
-        self._mod_table = dict(keys={k: i for i, k in enumerate(keys)}, table=table, guidance=float(gd[0]),
-                               pooled_ptr=pooled.data_ptr())
+        if not hasattr(self, "_mod_tables") or len(self._mod_tables) > 4:
+            self._mod_tables = {}
+        self._mod_tables[pooled.data_ptr()] = dict(keys={k: i for i, k in enumerate(keys)}, table=table,
+                                                   guidance=float(gd[0]))
+
+    def clear_modulations(self):
+        self._mod_tables = {}
 
     def _lookup_modulation(self, ts, gd, pooled) -> Optional[Modulation]:
-        mt = getattr(self, "_mod_table", None)
-        if mt is None or mt["pooled_ptr"] != pooled.data_ptr() or mt["guidance"] != float(gd[0]):
+        mt = getattr(self, "_mod_tables", {}).get(pooled.data_ptr())
+        if mt is None or mt["guidance"] != float(gd[0]):
             return None
         i = mt["keys"].get(float(ts[0]))
         return None if i is None else Modulation(mt["table"][i:i + 1], self.cfg_model.d)
@@ -452,12 +457,13 @@ class FluxTransformer2DModel:
                 img_ids=None, txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True):
         image_rotary_emb = self.pos_embed(torch.cat((txt_ids.cpu(), img_ids.cpu()), dim=0), self.device)
         return self._run(hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance,
-                         image_rotary_emb, return_dict)
+                         image_rotary_emb, return_dict, joint_attention_kwargs)
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
-    def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict):
+    def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict,
+             joint_attention_kwargs=None):
         """Shared body of the vanilla and the RegionE forward (inplace.py:469-576)."""
         assert hidden_states.shape[0] == 1, "harness engine runs one image per forward"
         M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
@@ -473,7 +479,7 @@ class FluxTransformer2DModel:
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
-        ctx = FwdCtx(ws, T, M, mods)
+        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"))
         for block in self.transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
         for block in self.single_transformer_blocks:
@@ -536,18 +542,26 @@ class FluxKontextPipeline:
         self.scheduler.set_timesteps(sigmas=sigmas, mu=mu)
         return latents, image_latents, latent_ids, text_ids, h_tok, w_tok
 
+    def _precompute(self, timesteps, guidance, dtype, *pooled_list):
+        if hasattr(self.transformer, "precompute_modulations"):
+            self.transformer.clear_modulations()
+            for pooled in pooled_list:
+                if pooled is not None:
+                    self.transformer.precompute_modulations([t.expand(1).to(dtype) / 1000 for t in timesteps], guidance, pooled)
+
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, guidance_scale=2.5, latents=None, generator=None, output_type="latent",
-                 return_dict=True, callback_on_step_end=None):
+                 return_dict=True, callback_on_step_end=None, true_cfg_scale: float = 1.0,
+                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None):
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
             image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
         timesteps = self.scheduler.timesteps
         guidance = torch.full([1], guidance_scale, dtype=torch.float32)
+        do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None
         self.scheduler.set_begin_index(0)
-        if hasattr(self.transformer, "precompute_modulations"):
-            self.transformer.precompute_modulations([t.expand(1).to(latents.dtype) / 1000 for t in timesteps], guidance,
-                                                    pooled_prompt_embeds)
+        self._precompute(timesteps, guidance, latents.dtype, pooled_prompt_embeds,
+                         negative_pooled_prompt_embeds if do_true_cfg else None)
         for i, t in enumerate(timesteps):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
@@ -556,6 +570,12 @@ class FluxKontextPipeline:
                                           encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_ids,
                                           return_dict=False)[0]
             noise_pred = noise_pred[:, : latents.size(1)]
+            if do_true_cfg:
+                neg = self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance,
+                                       pooled_projections=negative_pooled_prompt_embeds,
+                                       encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,
+                                       img_ids=latent_ids, return_dict=False)[0][:, : latents.size(1)]
+                noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             if callback_on_step_end is not None:
                 callback_on_step_end(self, i, t, {"latents": latents})

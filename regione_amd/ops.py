@@ -134,6 +134,18 @@ def avd_apply(cache: torch.Tensor, ratio: float, ids: Optional[torch.Tensor] = N
     return out.unsqueeze(0) if cache.dim() == 3 else out
 
 
+CFG_PLAIN, CFG_STEP1X_RESCALE, CFG_QWEN_NORM = 0, 1, 2
+
+
+def cfg_combine(pos: torch.Tensor, neg: torch.Tensor, scale: float, mode: int = CFG_PLAIN, power: float = 0.4) -> torch.Tensor:
+    p, n = _rows(pos), _rows(neg)
+    out = torch.empty_like(p)
+    rc = _lib.lib().rgn_cfg_combine(_p(p), _p(n), _p(out), _dt(p), float(scale), mode, float(power), p.shape[0],
+                                    p.shape[1], _stream())
+    _lib.check(rc, "rgn_cfg_combine")
+    return out.unsqueeze(0) if pos.dim() == 3 else out
+
+
 # ---------------------------------------------------------------------------------------------
 # MMDiT block kernels
 # ---------------------------------------------------------------------------------------------

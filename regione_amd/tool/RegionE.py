@@ -50,7 +50,7 @@ class RegionEHelper(object):
         self.pipeline = self._family().unwarp_modules(self.pipeline)
 
     def set_params(self, num_inference_steps=28, warmup_step=None, post_step=None, refresh_step=None, threshold=None,
-                   cache_threshold=None, erosion_dilation=None):
+                   cache_threshold=None, erosion_dilation=None, strict_reference=None):
         assert num_inference_steps == 28, "num_inference_steps must be 28"
         if warmup_step is not None: self.config['warmup_step'] = warmup_step
         if post_step is not None: self.config['post_step'] = post_step
@@ -58,4 +58,5 @@ class RegionEHelper(object):
         if threshold is not None: self.config['threshold'] = threshold
         if cache_threshold is not None: self.config['cache_threshold'] = cache_threshold
         if erosion_dilation is not None: self.config['erosion_dilation'] = erosion_dilation
+        if strict_reference is not None: self.config['strict_reference'] = strict_reference   # extension, see FluxKontext/inplace.py
         print(f"RegionEHelper: set_params {self.config}")

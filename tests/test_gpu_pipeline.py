@@ -105,3 +105,39 @@ def test_toy_mmdit_regione_vs_reference_fixture(golden):
     van = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(), height=h * 16,
                width=w * 16, latents=lat.cuda(), guidance_scale=2.5, return_dict=False)[0].cpu()
     assert torch.isfinite(van.float()).all()
+
+
+def test_toy_true_cfg_strict_reference_and_per_branch_caches(golden):
+    """FLUX true-CFG on the HIP engine: strict_reference=True (one cache shared by both branches,
+    quirk A-4) must match the reference fixture; the default (one cache per branch tag) must run and
+    differ only slightly (it is the intentional fix)."""
+    g = golden("toy_bf16_cfg")
+    h, w, T = g["h"], g["w"], g["T"]
+    cfg = synth.FluxConfig(**synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=g["w_std"])
+    lat, _, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=g["seed"], dtype=torch.bfloat16)
+    _, _, nprompt, npooled = synth.make_edit_inputs(h, w, T, cfg, seed=g["nseed"], dtype=torch.bfloat16)
+    img = g["image_latents"]
+    outs = {}
+    for strict in (True, False):
+        pipe = _toy_pipe(wts, cfg)
+        helper = RegionEHelper(pipe)
+        helper.set_params(threshold=g["threshold"], strict_reference=strict)
+        helper.enable()
+        trace = {}
+        outs[strict] = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(),
+                            height=h * 16, width=w * 16, latents=lat.cuda(), guidance_scale=2.5,
+                            true_cfg_scale=g["true_cfg_scale"], negative_prompt_embeds=nprompt.cuda(),
+                            negative_pooled_prompt_embeds=npooled.cuda(), return_dict=False, trace=trace)[0].cpu()
+        assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+        if strict:
+            assert torch.equal(pipe._regione_manager.edited_ids.cpu().squeeze(0).int(), g["edited_ids"].squeeze(0))
+            for i in (0, 5, 6, 15, 27):
+                assert O.psnr(trace["noise_pred"][i].cpu(), g[f"np{i}"]) > 35.0, i
+            ncache = {len(b.attn.processor.caches) for b in pipe.transformer.transformer_blocks}
+            assert ncache == {1}
+        else:
+            ncache = {len(b.attn.processor.caches) for b in pipe.transformer.single_transformer_blocks}
+            assert ncache == {2}                                   # cond + uncond
+    assert O.psnr(outs[True], g["final"]) >= 40.0
+    assert torch.isfinite(outs[False].float()).all() and O.psnr(outs[False], g["final"]) > 20.0

@@ -147,3 +147,29 @@ def test_partition_inside_scheduler_step_matches_reference(golden, name):
     out = ops.euler_step(sample.cuda(), v.cuda(), float(sigmas[6] - sigmas[5]), mask, float(sigmas[refresh0] - sigmas[5]))
     # fixture lat5 is recorded after Manager.step, i.e. already compacted to the edited rows
     assert torch.equal(ops.gather_rows(out, e).cpu(), g["lat5"])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_cfg_combine_modes(dtype):
+    """The three CFG combines of the reference loops, eager op sequence on CPU vs the fused kernel."""
+    from regione_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    K = 1000
+    pos = torch.randn(1, K, 64, generator=gen).to(dtype)
+    neg = (pos.float() + 0.3 * torch.randn(1, K, 64, generator=gen)).to(dtype)
+    neg[0, :100] = pos[0, :100] + (0.01 * torch.randn(100, 64, generator=gen)).to(dtype)     # ||diff|| < 1 rows
+    s = 6.0
+    ref0 = neg + s * (pos - neg)                                                   # FluxKontext/inplace.py:364
+    out0 = ops.cfg_combine(pos.cuda(), neg.cuda(), s, ops.CFG_PLAIN).cpu()
+    assert torch.equal(out0, ref0)
+    diff = pos - neg                                                                # Step1XEdit/inplace.py:402-407
+    dn = torch.norm(diff, dim=2, keepdim=True)
+    f = torch.where(dn > 1.0, torch.pow(dn, 0.4), torch.where(dn < 1.0, torch.ones_like(dn), dn))
+    ref1 = neg + s * (pos - neg) / f
+    out1 = ops.cfg_combine(pos.cuda(), neg.cuda(), s, ops.CFG_STEP1X_RESCALE, 0.4).cpu()
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 1e-5                              # row-norm reduction order differs
+    assert float((out1.float() - ref1.float()).abs().max()) <= tol * float(ref1.float().abs().max())
+    comb = neg + s * (pos - neg)                                                    # QwenImageEdit/inplace.py:401-405
+    ref2 = comb * (torch.norm(pos, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
+    out2 = ops.cfg_combine(pos.cuda(), neg.cuda(), s, ops.CFG_QWEN_NORM).cpu()
+    assert float((out2.float() - ref2.float()).abs().max()) <= tol * float(ref2.float().abs().max())

@@ -1,0 +1,74 @@
+"""CPU, world_size 2, gloo: the N>1 plumbing of the image-sharded path (no GPU needed)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_images, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from regione_amd import dist as D
+    dist = D.init("gloo")
+    ids = D.shard_images(n_images, world, rank)
+    # stand-in "edit": the latent of image j is a deterministic function of j only
+    local = [torch.full((1, 8, 64), float(j)).to(torch.bfloat16) + torch.arange(64).to(torch.bfloat16) for j in ids]
+    holder = {}
+
+    def job():
+        holder["all"] = D.gather_latents(local, ids, n_images, dist)
+    el = D.timed(job, lambda: None, dist)
+    ok = all(torch.equal(holder["all"][j], torch.full((1, 8, 64), float(j)).to(torch.bfloat16) + torch.arange(64).to(torch.bfloat16))
+             for j in range(n_images))
+    q.put((rank, ids, ok, el))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_images):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_images, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_image_sharding_even_batch():
+    res = _run(8)
+    assert res[0][1] == [0, 2, 4, 6] and res[1][1] == [1, 3, 5, 7]
+    assert all(r[2] for r in res)
+    assert res[0][3] == res[1][3] > 0            # MAX-reduced time is identical on every rank
+
+
+def test_image_sharding_ragged_batch():
+    res = _run(5)                                # assets/data.jsonl has 5 prompts
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    assert all(r[2] for r in res)
+
+
+def test_shard_images_partition():
+    from regione_amd import dist as D
+    for n in (0, 1, 5, 8, 17):
+        for w in (1, 2, 4, 8):
+            parts = [D.shard_images(n, w, r) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1

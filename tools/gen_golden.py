@@ -150,13 +150,14 @@ def make_fake_pipeline(ns, transformer, latents, image_latents, ids_full, prompt
     pipe.transformer = transformer
     L = latents.shape[1]
     text_ids = torch.zeros(txt_len, 3)
-    pipe.encode_prompt = lambda **k: (prompt, pooled, text_ids)
+    pipe.encode_prompt = lambda **k: ((k.get("prompt_embeds") if k.get("prompt_embeds") is not None and k["prompt_embeds"].dim() == 3 and k["prompt_embeds"].shape[1] > 1 else prompt),
+                                      (k.get("pooled_prompt_embeds") if k.get("pooled_prompt_embeds") is not None and k["pooled_prompt_embeds"].shape[-1] > 1 else pooled), text_ids)
     pipe.prepare_latents = lambda *a, **k: (latents.clone(), image_latents.clone(), ids_full[:L].clone(),
                                             ids_full[L:].clone())
     return pipe
 
 
-def run_reference_loop(ns, pipe, cfg, h_tok, w_tok, record):
+def run_reference_loop(ns, pipe, cfg, h_tok, w_tok, record, extra=None):
     """Drive the reference __call__ and record per-step state through monkey-patched hooks."""
     ip = ns.flux
     ip.warp_modules(pipe, **cfg)
@@ -199,7 +200,7 @@ def run_reference_loop(ns, pipe, cfg, h_tok, w_tok, record):
         img = torch.zeros(1, 16, 2 * h_tok, 2 * w_tok)           # takes the "already latent" branch
         out = pipe(image=img, prompt_embeds=torch.zeros(1, 1, 1), pooled_prompt_embeds=torch.zeros(1, 1),
                    height=h_tok * 16, width=w_tok * 16, max_area=h_tok * 16 * w_tok * 16,
-                   num_inference_steps=28, guidance_scale=2.5, output_type="latent", return_dict=False)
+                   num_inference_steps=28, guidance_scale=2.5, output_type="latent", return_dict=False, **(extra or {}))
     finally:
         ip.MANAGER.step = orig_mstep
     L_ = record["noise_pred"][0].shape[1]
@@ -341,6 +342,49 @@ def gen_kv_and_toy(ns):
         print("   lens:", rec["len"], " K_e =", rec["edited_ids"].shape[1])
 
 
+def gen_toy_cfg(ns):
+    """FLUX true-CFG (true_cfg_scale > 1, sequential cond / uncond forwards sharing ONE K/V cache,
+    reference quirk A-4) at toy dims."""
+    dtype = torch.bfloat16
+    cfg = synth.FluxConfig(**synth.TOY)
+    h = w = 16
+    L, T = h * w, 32
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=dtype, w_std=0.05)
+    model = ref_stubs.FluxTransformer2DModel(in_channels=cfg.in_channels, n_double=cfg.n_double, n_single=cfg.n_single,
+                                             heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim,
+                                             pooled_dim=cfg.pooled_dim, axes_dim=cfg.axes_dim).to(dtype)
+    load_weights_into(model, wts)
+    model.eval()
+    latents, image_latents, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=42, dtype=dtype)
+    _, _, nprompt, npooled = synth.make_edit_inputs(h, w, T, cfg, seed=43, dtype=dtype)
+    base = load_npz("toy_bf16")
+    image_latents = base["image_latents"]
+    ids_full = synth.flux_latent_ids(h, w)
+    pipe = make_fake_pipeline(ns, model, latents, image_latents, ids_full, prompt, pooled, T)
+    rcfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.5,
+                cache_threshold=0.04, erosion_dilation=True)
+    rec = {k: [] for k in ("noise_pred", "prev_sample", "len", "ids_len", "prev_refresh", "next_refresh", "latents")}
+    with torch.no_grad():
+        run_reference_loop(ns, pipe, rcfg, h, w, rec, extra=dict(
+            true_cfg_scale=4.0, negative_prompt_embeds=nprompt, negative_pooled_prompt_embeds=npooled))
+    d = dict(h=h, w=w, T=T, seed=42, nseed=43, true_cfg_scale=4.0, threshold=0.5, w_std=0.05,
+             image_latents=image_latents, len=np.array(rec["len"]), final=rec["final"], kinds=np.array(rec["kinds"]),
+             edited_ids=rec["edited_ids"].to(torch.int32),
+             np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+             lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]))
+    for i in (0, 5, 6, 15, 27):
+        d[f"np{i}"] = rec["noise_pred"][i]
+        d[f"lat{i}"] = rec["latents"][i]
+    save("toy_bf16_cfg", d)
+    print("   lens:", rec["len"][:8], " K_e =", rec["edited_ids"].shape[1], "kinds", "".join(rec["kinds"]))
+
+
+def load_npz(name):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_golden
+    return load_golden(name)
+
+
 def main():
     ns = ref_stubs.install()
     torch.set_num_threads(8)
@@ -355,6 +399,8 @@ def main():
         gen_loop(ns)
     if "toy" in which:
         gen_kv_and_toy(ns)
+    if "toycfg" in which or "toy" in which:
+        gen_toy_cfg(ns)
 
 
 if __name__ == "__main__":
