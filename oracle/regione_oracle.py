@@ -36,6 +36,10 @@ GAMMA = {
     "flux": [0.8352, 0.9986, 1.0090, 1.0097, 1.0161, 1.0152, 1.0160, 1.0173, 1.0177,
              1.0199, 1.0213, 1.0203, 1.0257, 1.0236, 1.0235, 1.0278, 1.0302, 1.0311,
              1.0352, 1.0371, 1.0391, 1.0459, 1.0498, 1.0581, 1.0693, 1.0866, 1.1090],
+    # Step1XEdit/inplace.py:47-49
+    "step1x": [0.9746, 0.9593, 1.0036, 1.0084, 1.0106, 1.0114, 1.0138, 1.0163, 1.0152,
+               1.0163, 1.0197, 1.0186, 1.0219, 1.0218, 1.0223, 1.0266, 1.0272, 1.0305,
+               1.0311, 1.0362, 1.0385, 1.0423, 1.0500, 1.0536, 1.0671, 1.0866, 1.1015],
 }
 
 
@@ -385,6 +389,8 @@ def time_text_embed(w, timestep, guidance, pooled):
     """[EXT] CombinedTimestepGuidanceTextProjEmbeddings."""
     p = "time_text_embed."
     t = _mlp_embed(w, p + "timestep_embedder", timestep_embedding(timestep).to(pooled.dtype))
+    if guidance is None:     # Step1X-Edit: temb = time_embed(t) + vec_embed(y)  (Step1XEdit/inplace.py:519-520)
+        return t + _mlp_embed(w, p + "text_embedder", pooled)
     g = _mlp_embed(w, p + "guidance_embedder", timestep_embedding(guidance).to(pooled.dtype))
     return t + g + _mlp_embed(w, p + "text_embedder", pooled)
 
@@ -497,7 +503,7 @@ def transformer_forward(w, cfg: FluxCfg, st: RegionState, caches: List[KVCache],
     """inplace.py:413-576.  `timestep` arrives already divided by 1000 (inplace.py:336)."""
     h = _lin(w, "x_embedder", hidden)
     ts = timestep.to(h.dtype) * 1000
-    g = guidance.to(h.dtype) * 1000
+    g = guidance.to(h.dtype) * 1000 if guidance is not None else None
     temb = time_text_embed(w, ts, g, pooled)
     c = _lin(w, "context_embedder", enc)
     rope_q = flux_pos_embed(torch.cat((txt_ids, img_ids), 0), cfg.axes_dim)            # :495-496
@@ -520,6 +526,26 @@ def transformer_forward(w, cfg: FluxCfg, st: RegionState, caches: List[KVCache],
 # --------------------------------------------------------------------------------------
 # a11  denoise loop
 # --------------------------------------------------------------------------------------
+def process_diff_norm(diff_norm, k):
+    """[EXT] Step1XEditPipeline.process_diff_norm (call site Step1XEdit/inplace.py:407)."""
+    return torch.where(diff_norm > 1.0, torch.pow(diff_norm, k),
+                       torch.where(diff_norm < 1.0, torch.ones_like(diff_norm), diff_norm))
+
+
+def cfg_combine(family, pos, neg, scale, t=None, truncate=0.93, power=0.4):
+    """flux: inplace.py:364 | step1x: Step1XEdit/inplace.py:401-410 | qwen: QwenImageEdit/inplace.py:401-405."""
+    if family == "step1x":
+        if t.item() > truncate:
+            diff = pos - neg
+            diff_norm = torch.norm(diff, dim=(2), keepdim=True)
+            return neg + scale * (pos - neg) / process_diff_norm(diff_norm, k=power)
+        return neg + scale * (pos - neg)
+    comb = neg + scale * (pos - neg)
+    if family == "qwen":
+        return comb * (torch.norm(pos, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
+    return comb
+
+
 def denoise(model_fn, st: RegionState, latents, image_latents, latent_ids, txt_length, h_tok, w_tok,
             family="flux", regione=True, trace: Optional[dict] = None, neg_model_fn=None, true_cfg_scale: float = 1.0):
     """inplace.py:229-244,287-392 (true_cfg_scale = 1: FLUX-Kontext's normal, guidance-distilled use).
@@ -558,7 +584,7 @@ def denoise(model_fn, st: RegionState, latents, image_latents, latent_ids, txt_l
             noise_pred = model_fn(x, timesteps[i], ids)[:, :latents.size(1)]          # :336-347
             if neg_model_fn is not None and true_cfg_scale > 1:                       # true CFG, :349-364
                 neg = neg_model_fn(x, timesteps[i], ids)[:, :latents.size(1)]
-                noise_pred = neg + true_cfg_scale * (noise_pred - neg)
+                noise_pred = cfg_combine(family, noise_pred, neg, true_cfg_scale, timesteps[i])
             cache = noise_pred                                                        # :365
         if trace is not None:
             trace.setdefault("kind", []).append("C" if hit else ("F" if st.is_full_input_step() else "R"))

@@ -84,7 +84,7 @@ class AvdState:
         self.should_cache = False
 
 
-def avd_decide(M: FluxKontextManager, avd: AvdState, i: int, timesteps: torch.Tensor):
+def avd_decide(M: FluxKontextManager, avd: AvdState, i: int, timesteps: torch.Tensor, gamma: torch.Tensor = gamma):
     """inplace.py:295-313 on HOST tensors: gamma[i-1] is a 0-dim fp16 tensor, timesteps are fp32, so
     `ratio` is fp32 and `accumulate` is carried in fp32 - the same dtype path as the reference's
     device tensors, minus the two implicit device->host syncs per step (quirk A-7)."""

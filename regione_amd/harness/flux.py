@@ -302,7 +302,7 @@ class FluxTransformer2DModel:
 
     def __init__(self, cfg: FluxConfig, device="cuda"):
         self.cfg_model = cfg
-        self.config = _Cfg(in_channels=cfg.in_channels, guidance_embeds=True)
+        self.config = _Cfg(in_channels=cfg.in_channels, guidance_embeds=cfg.guidance_embeds)
         self.device = torch.device(device)
         self.dtype = torch.bfloat16
         self.gradient_checkpointing = False
@@ -414,8 +414,11 @@ class FluxTransformer2DModel:
             return ops.gemv(h, getattr(self, f"tte_{e}_linear_2_weight"), getattr(self, f"tte_{e}_linear_2_bias"),
                             silu_input=True)
         te = timestep_embedding(timestep.detach().float().cpu()).to(torch.bfloat16).to(self.device)
+        t, p = mlp("timestep_embedder", te), mlp("text_embedder", pooled)
+        if not self.cfg_model.guidance_embeds or guidance is None:
+            return t + p          # Step1X-Edit: temb = time_embed(t) + vec_embed(y)
         ge = timestep_embedding(guidance.detach().float().cpu()).to(torch.bfloat16).to(self.device)
-        t, g, p = mlp("timestep_embedder", te), mlp("guidance_embedder", ge), mlp("text_embedder", pooled)
+        g = mlp("guidance_embedder", ge)
         return (t + g) + p        # two bf16 adds, same order as the module (tiny [1, d] tensors)
 
     # -- all-step modulation table ----------------------------------------------------------------------
@@ -425,7 +428,7 @@ class FluxTransformer2DModel:
         steps - the 6.5 GB of AdaLN weights stream from HBM once per edit instead of once per computed
         step.  `forward` looks rows up by the bf16 timestep value and falls back to the per-step GEMV."""
         d = self.cfg_model.d
-        gd = guidance.to(torch.bfloat16) * 1000
+        gd = guidance.to(torch.bfloat16) * 1000 if guidance is not None else None
         keys, rows = [], []
         for ts in timesteps_div1000:
             tsb = ts.to(torch.bfloat16) * 1000
@@ -440,14 +443,14 @@ class FluxTransformer2DModel:
         if not hasattr(self, "_mod_tables") or len(self._mod_tables) > 4:
             self._mod_tables = {}
         self._mod_tables[pooled.data_ptr()] = dict(keys={k: i for i, k in enumerate(keys)}, table=table,
-                                                   guidance=float(gd[0]))
+                                                   guidance=None if gd is None else float(gd[0]))
 
     def clear_modulations(self):
         self._mod_tables = {}
 
     def _lookup_modulation(self, ts, gd, pooled) -> Optional[Modulation]:
         mt = getattr(self, "_mod_tables", {}).get(pooled.data_ptr())
-        if mt is None or mt["guidance"] != float(gd[0]):
+        if mt is None or mt["guidance"] != (None if gd is None else float(gd[0])):
             return None
         i = mt["keys"].get(float(ts[0]))
         return None if i is None else Modulation(mt["table"][i:i + 1], self.cfg_model.d)
@@ -474,7 +477,7 @@ class FluxTransformer2DModel:
         ops.gemm(hidden_states[0], self.x_embedder_weight, self.x_embedder_bias, ws.x[T:R])
         ops.gemm(encoder_hidden_states[0], self.context_embedder_weight, self.context_embedder_bias, ws.x[:T])
         ts = timestep.to(torch.bfloat16) * 1000                       # inplace.py:471
-        gd = guidance.to(torch.bfloat16) * 1000
+        gd = guidance.to(torch.bfloat16) * 1000 if guidance is not None else None
         mods = self._lookup_modulation(ts, gd, pooled)
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)

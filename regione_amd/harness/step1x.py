@@ -1,0 +1,100 @@
+"""Step1X-Edit-shaped harness: the FLUX trunk [EXT: same double/single MMDiT blocks] with
+temb = time_embed(t) + vec_embed(y) (no guidance embedder) and a batched-CFG pipeline
+(/root/reference/RegionE/Step1XEdit/inplace.py:381-410).
+
+The Qwen2.5-VL `connector` that turns the VLM hidden states into (encoder_hidden_states, y)
+(Step1XEdit/inplace.py:514-516) is [EXT] and outside the hot path: the harness takes its OUTPUTS
+(`prompt_embeds` [1,T,joint] and the pooled vector `y` [1,pooled]) as pipeline inputs.
+
+Batch = 2 of the reference's CFG forward is executed as two passes over the single-image engine, the
+branch index travelling as the K/V-cache tag ('cond' / 'uncond'); rows of a batch never interact in
+the model, so this is numerically the batched forward.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..synth import FluxConfig
+from . import flux as H
+
+
+class Step1XEditAttnProcessor(H.FluxAttnProcessor):
+    pass
+
+
+class Step1XEditTransformer2DModel(H.FluxTransformer2DModel):
+    def __init__(self, cfg: FluxConfig, device="cuda"):
+        assert not cfg.guidance_embeds, "Step1X-Edit has no guidance embedder"
+        super().__init__(cfg, device)
+        self._vec = None
+
+    def set_vec(self, y_rows):
+        """Connector output y per batch row (cond, uncond)."""
+        self._vec = list(y_rows)
+
+    def connector(self, encoder_hidden_states, timestep, prompt_embeds_mask):
+        return encoder_hidden_states, self._vec
+
+    def forward(self, hidden_states, encoder_hidden_states=None, prompt_embeds_mask=None, timestep=None, img_ids=None,
+                txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True):
+        image_rotary_emb = self.pos_embed(torch.cat((txt_ids.cpu(), img_ids.cpu()), dim=0), self.device)
+        return self._run_batched(hidden_states, encoder_hidden_states, prompt_embeds_mask, timestep, image_rotary_emb,
+                                 return_dict)
+
+    def _run_batched(self, hidden_states, encoder_hidden_states, prompt_embeds_mask, timestep, image_rotary_emb,
+                     return_dict):
+        enc, y = self.connector(encoder_hidden_states, timestep, prompt_embeds_mask)
+        outs = []
+        for b in range(hidden_states.shape[0]):
+            tag = "cond" if b == 0 else "uncond"
+            outs.append(self._run(hidden_states[b:b + 1], enc[b:b + 1], y[b], timestep[b:b + 1], None, image_rotary_emb,
+                                  False, {"tag": tag})[0])
+        out = torch.cat(outs, 0)
+        return (out,) if not return_dict else H._Cfg(sample=out)
+
+
+class Step1XEditPipelineOutput(H._Cfg):
+    pass
+
+
+class Step1XEditPipeline(H.FluxKontextPipeline):
+    """Vanilla full-token loop with batched true-CFG (reference defaults true_cfg_scale = 6.0)."""
+
+    def process_diff_norm(self, diff_norm, k):   # kept for API parity; the arithmetic runs in rgn_cfg_combine
+        raise NotImplementedError("fused into ops.cfg_combine(mode=CFG_STEP1X_RESCALE)")
+
+    def _cfg(self, noise_pred, t, true_cfg_scale, timesteps_truncate, process_norm_power):
+        pos, neg = noise_pred[0:1], noise_pred[1:2]
+        mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN      # inplace.py:401
+        return ops.cfg_combine(pos.contiguous(), neg.contiguous(), true_cfg_scale, mode, process_norm_power)
+
+    def _batched_inputs(self, x, prompt_embeds, negative_prompt_embeds):
+        return torch.cat((x, x), dim=0), torch.cat((prompt_embeds, negative_prompt_embeds), dim=0)
+
+    @torch.no_grad()
+    def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
+                 negative_pooled_prompt_embeds=None, height=1024, width=1024, num_inference_steps=28,
+                 true_cfg_scale=6.0, guidance_scale=6.0, latents=None, generator=None, output_type="latent",
+                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4):
+        latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+        timesteps = self.scheduler.timesteps
+        self.scheduler.set_begin_index(0)
+        tr = self.transformer
+        if hasattr(tr, "set_vec"):
+            tr.set_vec((pooled_prompt_embeds, negative_pooled_prompt_embeds))
+        self._precompute(timesteps, None, latents.dtype, pooled_prompt_embeds, negative_pooled_prompt_embeds)
+        for i, t in enumerate(timesteps):
+            x, pe = self._batched_inputs(torch.cat([latents, image_latents], dim=1), prompt_embeds, negative_prompt_embeds)
+            timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            timestep = torch.cat((timestep, timestep), dim=0)
+            noise_pred = tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=pe,
+                            prompt_embeds_mask=None, txt_ids=text_ids, img_ids=latent_ids, return_dict=False)[0]
+            noise_pred = noise_pred[:, : latents.size(1)]
+            noise_pred = self._cfg(noise_pred, t, true_cfg_scale, timesteps_truncate, process_norm_power)
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+        if not return_dict:
+            return (latents,)
+        return Step1XEditPipelineOutput(images=latents)

@@ -24,6 +24,7 @@ class FluxConfig:
     pooled_dim: int = 768
     axes_dim: Tuple[int, ...] = (16, 56, 56)
     mlp_ratio: int = 4
+    guidance_embeds: bool = True          # False: Step1X-Edit style temb = time_embed + vec_embed(y)
 
     @property
     def d(self) -> int:
@@ -48,6 +49,8 @@ def flux_param_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
     lin("x_embedder", d, cfg.in_channels)
     lin("context_embedder", d, cfg.joint_dim)
     for e, din in (("timestep_embedder", 256), ("guidance_embedder", 256), ("text_embedder", cfg.pooled_dim)):
+        if e == "guidance_embedder" and not cfg.guidance_embeds:
+            continue
         lin(f"time_text_embed.{e}.linear_1", d, din)
         lin(f"time_text_embed.{e}.linear_2", d, d)
     for i in range(cfg.n_double):

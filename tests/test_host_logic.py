@@ -34,6 +34,11 @@ def cpu_ops(monkeypatch):
         c = O.ids_gather(cache, ids) if ids is not None else cache
         return c * torch.tensor(ratio)
 
+    def cfg(pos, neg, scale, mode=0, power=0.4):
+        fam = {0: "flux", 1: "step1x", 2: "qwen"}[mode]
+        return O.cfg_combine(fam, pos, neg, scale, t=torch.tensor(1e9), power=power)
+
+    monkeypatch.setattr(ops, "cfg_combine", cfg)
     monkeypatch.setattr(ops, "arp_partition", arp)
     monkeypatch.setattr(ops, "euler_step", euler)
     monkeypatch.setattr(ops, "avd_apply", avd)
@@ -146,3 +151,53 @@ def test_avd_decision_is_data_independent_plan(golden):
                 M.prev_refresh_step = M.next_refresh_step
         assert "".join(got) == "".join(plan).replace("S", "F")
     assert "".join(O.derive_schedule(4096)).count("C") == 14      # 9 F, 5 R, 14 C
+
+
+class FakeTransformerB2(FakeTransformer):
+    """Batch-2 stand-in for Step1X's batched CFG forward (row 0 cond, row 1 uncond)."""
+
+    def __init__(self, tpos_full, tneg_full, w_tok, L, device="cpu"):
+        super().__init__(tpos_full, w_tok, L, device)
+        self.cfg_model = synth.FluxConfig(guidance_embeds=False)
+        self.t2 = (tpos_full.to(device), tneg_full.to(device))
+
+    def __call__(self, hidden_states=None, timestep=None, img_ids=None, **kw):
+        tok = (img_ids[:, 0] * self.L + img_ids[:, 1] * self.w_tok + img_ids[:, 2]).long().to(self.device)
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        outs = [((hidden_states[b:b + 1].float() - self.t2[b][tok[:n]][None]) * k).to(hidden_states.dtype)
+                for b in range(hidden_states.shape[0])]
+        return (torch.cat(outs, 0),)
+
+
+def step1x_case(g, device="cpu"):
+    from regione_amd.harness import step1x as HS
+    h, w = g["h"], g["w"]
+    dt = torch.bfloat16 if g["bf16"] else torch.float32
+    L = h * w
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=dt)
+    tpos = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    tneg = tpos + 0.05 * torch.randn(tpos.shape, generator=torch.Generator().manual_seed(g["nseed"]))
+    cond = img[0].float()
+    tr = FakeTransformerB2(torch.cat([tpos, cond], 0), torch.cat([tneg, cond], 0), w, L, device)
+    pipe = HS.Step1XEditPipeline(tr)
+    helper = RegionEHelper(pipe)
+    assert helper.config["threshold"] == 0.88 and helper.config["cache_threshold"] == 0.02      # tool/RegionE.py:3
+    helper.enable()
+    trace = {}
+    dummy = torch.zeros(1, 8, 4).to(dt)
+    out = pipe(image=img, prompt_embeds=dummy, negative_prompt_embeds=dummy, height=h * 16, width=w * 16, latents=lat,
+               true_cfg_scale=g["true_cfg_scale"], return_dict=False, trace=trace)[0]
+    return pipe, out, trace
+
+
+@pytest.mark.parametrize("name", ["s1x_loop_bf16_32", "s1x_loop_f32_16"])
+def test_step1x_product_loop_matches_reference_trace(golden, cpu_ops, name):
+    g = golden(name)
+    pipe, out, trace = step1x_case(g)
+    assert pipe.__class__.__name__ == "RegionEStep1XEditPipeline"
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    assert torch.equal(pipe._regione_manager.edited_ids.squeeze(0).int(), g["edited_ids"].squeeze(0))
+    assert [x.shape[1] for x in trace["latents"]] == g["len"].tolist()
+    assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
+    assert torch.equal(out, g["final"])

@@ -342,6 +342,99 @@ def gen_kv_and_toy(ns):
         print("   lens:", rec["len"], " K_e =", rec["edited_ids"].shape[1])
 
 
+class FakeTransformerB2:
+    """Batch-2 elementwise stand-in for Step1X's batched CFG forward (Step1XEdit/inplace.py:381-399):
+    row 0 (cond) is pulled towards target_pos, row 1 (uncond) towards target_neg."""
+
+    def __init__(self, tpos_full, tneg_full, w_tok, L):
+        self.config = ref_stubs._Cfg(in_channels=64, guidance_embeds=False)
+        self.transformer_blocks, self.single_transformer_blocks = [], []
+        self.t = (tpos_full, tneg_full)
+        self.w_tok, self.L = w_tok, L
+
+    def __call__(self, hidden_states=None, timestep=None, img_ids=None, **kw):
+        tok = (img_ids[:, 0] * self.L + img_ids[:, 1] * self.w_tok + img_ids[:, 2]).long()
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        outs = [((hidden_states[b:b + 1].float() - self.t[b][tok[:n]][None]) * k).to(hidden_states.dtype)
+                for b in range(hidden_states.shape[0])]
+        return (torch.cat(outs, 0),)
+
+
+def gen_step1x_loop(ns):
+    """Reference RegionEStep1XEditPipeline.__call__ (batched CFG B=2, norm-rescaled CFG, Step1X gamma)
+    with the elementwise fake transformer."""
+    import diffusers
+    ip = ns.step1x
+    for name, h, w, dtype, box in (("s1x_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),
+                                   ("s1x_loop_f32_16", 16, 16, torch.float32, (4, 11, 4, 11))):
+        fcfg = synth.FluxConfig()
+        latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
+        L = h * w
+        tpos = synth.region_target(h, w, box, image_latents, seed=7, ramp=0.9)
+        g = torch.Generator().manual_seed(11)
+        tneg = tpos + 0.05 * torch.randn(tpos.shape, generator=g)
+        cond = image_latents[0].float()
+        tr = FakeTransformerB2(torch.cat([tpos, cond], 0), torch.cat([tneg, cond], 0), w, L)
+        pipe = diffusers.Step1XEditPipeline()
+        pipe.scheduler = ref_stubs.FlowMatchEulerDiscreteScheduler()
+        pipe.transformer = tr
+        ids_full = synth.flux_latent_ids(h, w)
+        text_ids = torch.zeros(8, 3)
+        dummy = torch.zeros(1, 8, 4).to(dtype)
+        pipe.encode_image = lambda image, width, height, device, n: (image, None, None, width, height)
+        pipe.encode_prompt = lambda **k: (dummy, torch.ones(1, 8), text_ids)
+        pipe.prepare_latents = lambda *a, **k: (latents.clone(), image_latents.clone(), ids_full[:L].clone(),
+                                                ids_full[L:].clone())
+        cfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.88,
+                   cache_threshold=0.02, erosion_dilation=True)
+        ip.warp_modules(pipe, **cfg)
+        rec = {k: [] for k in ("noise_pred", "len", "prev_refresh", "latents", "calls")}
+        sch = pipe.scheduler
+        orig_step, orig_mstep = sch.step, ip.MANAGER.step
+
+        def step_hook(model_output, timestep, sample, **kw):
+            rec["noise_pred"].append(model_output.clone())
+            return orig_step(model_output, timestep, sample, **kw)
+
+        def mstep_hook(latent, latent_ids):
+            out = orig_mstep(latent, latent_ids)
+            rec["len"].append(out[0].shape[1])
+            rec["prev_refresh"].append(-1 if ip.MANAGER.prev_refresh_step is None else ip.MANAGER.prev_refresh_step)
+            rec["latents"].append(out[0].clone())
+            return out
+        inner = tr.__class__.__call__
+
+        class _Rec(tr.__class__):
+            def __call__(self, **kw):
+                rec["calls"].append((ip.MANAGER.current_step, kw["hidden_states"].shape[1]))
+                return inner(self, **kw)
+        tr.__class__ = _Rec
+        sch.step, ip.MANAGER.step = step_hook, mstep_hook
+        try:
+            out = pipe(image=torch.zeros(1, 3, 8, 8), prompt_embeds=dummy, prompt_embeds_mask=torch.ones(1, 8),
+                       negative_prompt_embeds=dummy, negative_prompt_embeds_mask=torch.ones(1, 8), height=h * 16,
+                       width=w * 16, num_inference_steps=28, true_cfg_scale=6.0, guidance_scale=6.0,
+                       output_type="latent", return_dict=False)
+        finally:
+            ip.MANAGER.step = orig_mstep
+        called = dict(rec["calls"])
+        kinds = ["C" if i not in called else ("F" if called[i] == 2 * L else "R") for i in range(28)]
+        d = dict(h=h, w=w, box=np.array(box), seed=42, tseed=7, nseed=11, ramp=0.9, bf16=int(dtype == torch.bfloat16),
+                 chk=float(latents.double().sum() + image_latents.double().sum() + tpos.double().sum() + tneg.double().sum()),
+                 kinds=np.array(kinds), len=np.array(rec["len"]), prev_refresh=np.array(rec["prev_refresh"]),
+                 final=out[0], edited_ids=ip.MANAGER.edited_ids.to(torch.int32), threshold=0.88, cache_threshold=0.02,
+                 true_cfg_scale=6.0,
+                 np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+                 lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]))
+        for i in (4, 5, 6, 7, 15, 16, 26):
+            d[f"lat{i}"] = rec["latents"][i]
+        for i in (0, 5, 6, 7):
+            d[f"np{i}"] = rec["noise_pred"][i]
+        save(name, d)
+        print("   kinds:", "".join(kinds), " K_e =", ip.MANAGER.edited_ids.shape[1], "/", L)
+
+
 def gen_toy_cfg(ns):
     """FLUX true-CFG (true_cfg_scale > 1, sequential cond / uncond forwards sharing ONE K/V cache,
     reference quirk A-4) at toy dims."""
@@ -401,6 +494,8 @@ def main():
         gen_kv_and_toy(ns)
     if "toycfg" in which or "toy" in which:
         gen_toy_cfg(ns)
+    if "step1x" in which or not sys.argv[1:]:
+        gen_step1x_loop(ns)
 
 
 if __name__ == "__main__":

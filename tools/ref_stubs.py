@@ -414,6 +414,19 @@ class _FakePipelineBase:
         yield _PB()
 
 
+class _FakeStep1XBase(_FakePipelineBase):
+    """[EXT] Step1XEditPipeline members the reference loop touches (Step1XEdit/inplace.py:186-460)."""
+
+    def process_diff_norm(self, diff_norm, k):
+        """[EXT] Step1X-Edit sampling: norm > 1 -> norm^k, norm < 1 -> 1, else norm."""
+        pow_result = torch.pow(diff_norm, k)
+        return torch.where(diff_norm > 1.0, pow_result,
+                           torch.where(diff_norm < 1.0, torch.ones_like(diff_norm), diff_norm))
+
+    def _output_process_image(self, image, img_info):
+        return image
+
+
 # --------------------------------------------------------------------------------------
 # stub installation + reference import
 # --------------------------------------------------------------------------------------
@@ -475,6 +488,13 @@ def install():
     tf.FluxTransformer2DModel = FluxTransformer2DModel
     sys.modules["diffusers"].FluxKontextPipeline = type("FluxKontextPipeline", (_FakePipelineBase,), {})
     sys.modules["diffusers.pipelines.flux"].FluxPipelineOutput = _BaseOutput
+    # Step1X-Edit (v1p1): same trunk; pipeline base needs process_diff_norm [EXT]
+    sys.modules["diffusers"].Step1XEditPipeline = type("Step1XEditPipeline", (_FakeStep1XBase,), {})
+    sys.modules["diffusers.pipelines.step1x_edit"].Step1XEditPipelineOutput = _BaseOutput
+    ts = sys.modules["diffusers.models.transformers.transformer_step1x_edit"]
+    ts.Step1XEditAttention = Attention
+    ts.Step1XEditAttnProcessor = FluxAttnProcessor
+    ts.Step1XEditTransformer2DModel = FluxTransformer2DModel
 
     pkg = types.ModuleType("RegionE")
     pkg.__path__ = [REF_ROOT + "/RegionE"]
@@ -485,5 +505,9 @@ def install():
     ns.flux_utils = importlib.import_module("RegionE.FluxKontext.utils")
     ns.flux.flash_attn = None
     ns.flux._partially_linear = partially_linear_cpu
+    ns.step1x = importlib.import_module("RegionE.Step1XEdit.inplace")
+    ns.step1x_utils = importlib.import_module("RegionE.Step1XEdit.utils")
+    ns.step1x.flash_attn = None
+    ns.step1x._partially_linear = partially_linear_cpu
     pkg._ns = ns
     return ns
