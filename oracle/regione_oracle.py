@@ -40,6 +40,10 @@ GAMMA = {
     "step1x": [0.9746, 0.9593, 1.0036, 1.0084, 1.0106, 1.0114, 1.0138, 1.0163, 1.0152,
                1.0163, 1.0197, 1.0186, 1.0219, 1.0218, 1.0223, 1.0266, 1.0272, 1.0305,
                1.0311, 1.0362, 1.0385, 1.0423, 1.0500, 1.0536, 1.0671, 1.0866, 1.1015],
+    # Step1XEditV1P2/inplace.py:48-50
+    "step1x_v1p2": [0.7936, 0.9807, 1.0063, 1.0205, 0.9946, 1.0125, 1.0116, 1.0125, 1.0172,
+                    1.0171, 1.0183, 1.0170, 1.0170, 1.0236, 1.0263, 1.0264, 1.0277, 1.0321,
+                    1.0338, 1.0361, 1.0396, 1.0454, 1.0492, 1.0566, 1.0696, 1.0879, 1.1179],
 }
 
 
@@ -534,7 +538,7 @@ def process_diff_norm(diff_norm, k):
 
 def cfg_combine(family, pos, neg, scale, t=None, truncate=0.93, power=0.4):
     """flux: inplace.py:364 | step1x: Step1XEdit/inplace.py:401-410 | qwen: QwenImageEdit/inplace.py:401-405."""
-    if family == "step1x":
+    if family in ("step1x", "step1x_v1p2"):
         if t.item() > truncate:
             diff = pos - neg
             diff_norm = torch.norm(diff, dim=(2), keepdim=True)

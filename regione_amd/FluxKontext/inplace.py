@@ -167,6 +167,21 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
         return H.FluxPipelineOutput(images=latents)
 
 
+def dual_rope_tables(transformer, MANAGER, txt_ids, img_ids):
+    """Query-row rotary table for this forward; also makes sure the FULL-id key table of this text
+    length exists (MANAGER.image_rotary_emb of the reference, inplace.py:495-500)."""
+    T = txt_ids.shape[0]
+    if T not in MANAGER.rope_full_by_T:
+        MANAGER.rope_full_by_T[T] = transformer.pos_embed(torch.cat((txt_ids.cpu(), MANAGER.latent_ids.cpu()), dim=0),
+                                                         transformer.device)
+    full = MANAGER.rope_full_by_T[T]
+    if MANAGER.image_rotary_emb is None:
+        MANAGER.image_rotary_emb = full
+    if img_ids.shape[0] == MANAGER.latent_ids.shape[0]:
+        return full
+    return MANAGER.rope_q_for(T, full)               # rows of the full table at [text ; edited ids]
+
+
 def RegionEFluxTransformer2DModelforward(self, hidden_states, encoder_hidden_states=None, pooled_projections=None,
                                          timestep=None, img_ids=None, txt_ids=None, guidance=None,
                                          joint_attention_kwargs=None, return_dict=True):
@@ -174,14 +189,7 @@ def RegionEFluxTransformer2DModelforward(self, hidden_states, encoder_hidden_sta
     one for the query rows (current, possibly compacted ids) and one for the keys (always the full id
     table, `MANAGER.image_rotary_emb`, :495-500)."""
     MANAGER: FluxKontextManager = self._regione_manager
-    if MANAGER.image_rotary_emb is None:
-        MANAGER.image_rotary_emb = self.pos_embed(torch.cat((txt_ids.cpu(), MANAGER.latent_ids.cpu()), dim=0), self.device)
-    if img_ids.shape[0] == MANAGER.latent_ids.shape[0]:
-        image_rotary_emb = MANAGER.image_rotary_emb
-    else:
-        if MANAGER.rope_q_region is None:
-            MANAGER.rope_q_region = tuple(ops.gather_rows(t, MANAGER.sel_rows) for t in MANAGER.image_rotary_emb)
-        image_rotary_emb = MANAGER.rope_q_region         # rows of the full table at [text ; edited ids]
+    image_rotary_emb = dual_rope_tables(self, MANAGER, txt_ids, img_ids)
     return self._run(hidden_states, encoder_hidden_states, pooled_projections, timestep, guidance, image_rotary_emb,
                      return_dict, joint_attention_kwargs)
 
@@ -260,7 +268,7 @@ class RegionEFluxAttnProcessor(H.FluxAttnProcessor):
             return c[0], c[1], None, skv, None
         # update: only rows [text ; T + edited_ids] are recomputed (:727-750)
         k, v, skv = self.caches[tag]
-        return k, v, MANAGER.sel_rows, skv, MANAGER.image_rotary_emb
+        return k, v, MANAGER.sel_rows_for(ctx.T), skv, MANAGER.rope_full_by_T[ctx.T]
 
 
 RegoionEFluxAttnProcessor2_0 = RegionEFluxAttnProcessor      # the reference's (misspelled) class name

@@ -102,12 +102,24 @@ class FluxKontextManager:
     def set_partition(self, edited_ids: torch.Tensor, unedited_ids: torch.Tensor, mask: torch.Tensor):
         """Called by the scheduler at step warmup-1 with the partition kernel's outputs."""
         self.edited_ids, self.unedited_ids, self.edited_mask = edited_ids, unedited_ids, mask
-        dev = edited_ids.device
-        T = self.txt_length
-        self.sel_rows = torch.cat((torch.arange(T, device=dev), edited_ids.squeeze(0) + T)).contiguous()
         self._ids_edited_host = None
+        self._sel_by_T, self._ropeq_by_T = {}, {}
+        self.sel_rows = self.sel_rows_for(self.txt_length)
         if self.image_rotary_emb is not None:
-            self.rope_q_region = tuple(ops.gather_rows(t, self.sel_rows) for t in self.image_rotary_emb)
+            self.rope_q_region = self.rope_q_for(self.txt_length, self.image_rotary_emb)
+
+    # per text length (the cond / uncond branches of Step1X-v1p2 and Qwen have different T:
+    # `selection` of Step1XEditV1P2/inplace.py:833,868)
+    def sel_rows_for(self, T: int) -> torch.Tensor:
+        if T not in self._sel_by_T:
+            dev = self.edited_ids.device
+            self._sel_by_T[T] = torch.cat((torch.arange(T, device=dev), self.edited_ids.squeeze(0) + T)).contiguous()
+        return self._sel_by_T[T]
+
+    def rope_q_for(self, T: int, full_table):
+        if T not in self._ropeq_by_T:
+            self._ropeq_by_T[T] = tuple(ops.gather_rows(t, self.sel_rows_for(T)) for t in full_table)
+        return self._ropeq_by_T[T]
 
     def _compact(self, latent, latent_ids):
         self.unedited_latent = ids_gather(latent, self.unedited_ids)
@@ -150,6 +162,8 @@ class FluxKontextManager:
         self.edited_ids = self.unedited_ids = self.unedited_latent = None
         self.edited_mask = self.sel_rows = self.rope_q_region = None
         self.image_rotary_emb = None
+        self.rope_full_by_T = {}         # text length -> (cos, sin) of [text ids ; FULL latent ids]
+        self._sel_by_T, self._ropeq_by_T = {}, {}
         self.latent_ids = latent_ids
         self.refresh_step_real_time = list(self.refresh_step)
 

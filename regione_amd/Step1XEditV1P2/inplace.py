@@ -1,13 +1,15 @@
-"""RegionE patch set for Step1X-Edit (v1p1) on the HIP kernels.
+"""RegionE patch set for Step1X-Edit v1p2 on the HIP kernels.
 
-Mirrors /root/reference/RegionE/Step1XEdit/inplace.py: `warp_modules` / `unwarp_modules` (:52-71),
-`RegionEStep1XEditPipeline.__call__` (:73-457), `RegionEStep1XEditTransformer2DModelforward` (:460-578),
-the scheduler (:581-695, identical to FLUX's) and `RegionEStep1XEditAttnProcessor` (:698-811, identical
-K/V-cache protocol).  Family deltas vs FLUX:
-  * CFG is BATCHED: one forward on [cond ; uncond] (:381-399); the partition sees the already
-    combined B = 1 prediction and the edited ids are shared by the pair (quirk A-5);
-  * norm-rescaled CFG for t > timesteps_truncate (:401-410) -> rgn_cfg_combine(mode 1);
-  * its own fitted gamma table (:47-49), default thresholds 0.88 / 0.02 (tool/RegionE.py:3).
+Mirrors /root/reference/RegionE/Step1XEditV1P2/inplace.py (`warp_modules` :53-62, `__call__` :76-545,
+forward :546-690, processor :806-945).  Family deltas:
+  * CFG is SEQUENTIAL: a 'cond' and an 'uncond' forward per computed step, the branch travelling as
+    `joint_attention_kwargs['tag']` into the processors, which keep one K/V cache per tag
+    (`k_cache_even/odd`, :800-888);
+  * the two branches have different text lengths (`txt_length` / `neg_txt_length`, selection :833,:868);
+  * norm-rescaled CFG (:421-430) -> rgn_cfg_combine(mode 1); v1p2 gamma table (:48-50).
+Out of scope (VLM prompting, not the hot path): the thinking / reflection retry loop (:192-212,470-486)
+and `text_token_mapping` ([EXT] extra text projection, :606-609) - the harness consumes the connector /
+mapping OUTPUTS as prompt embeddings.
 """
 from __future__ import annotations
 
@@ -19,18 +21,18 @@ from .. import ops
 from ..FluxKontext import inplace as fk
 from ..harness import flux as H
 from ..harness import step1x as HS
-from .utils import Step1XEditManager, ids_gather
+from .utils import Step1XEditV1P2Manager, ids_gather
 
-gamma = torch.tensor([0.9746, 0.9593, 1.0036, 1.0084, 1.0106, 1.0114, 1.0138, 1.0163, 1.0152,
-                      1.0163, 1.0197, 1.0186, 1.0219, 1.0218, 1.0223, 1.0266, 1.0272, 1.0305,
-                      1.0311, 1.0362, 1.0385, 1.0423, 1.0500, 1.0536, 1.0671, 1.0866, 1.1015], dtype=torch.float16)
+gamma = torch.tensor([0.7936, 0.9807, 1.0063, 1.0205, 0.9946, 1.0125, 1.0116, 1.0125, 1.0172,
+                      1.0171, 1.0183, 1.0170, 1.0170, 1.0236, 1.0263, 1.0264, 1.0277, 1.0321,
+                      1.0338, 1.0361, 1.0396, 1.0454, 1.0492, 1.0566, 1.0696, 1.0879, 1.1179], dtype=torch.float16)
 
 RegionEFlowMatchEulerDiscreteScheduler = fk.RegionEFlowMatchEulerDiscreteScheduler
 RegionEStep1XEditAttnProcessor = fk.RegionEFluxAttnProcessor
 
 
 def warp_modules(pipeline, **args):
-    manager = Step1XEditManager()
+    manager = Step1XEditV1P2Manager()
     manager.set_parameters(dict(args))
     pipeline._regione_manager = manager
     pipeline._regione_vanilla_class = pipeline.__class__
@@ -49,7 +51,7 @@ def warp_modules(pipeline, **args):
 
 
 def unwarp_modules(pipeline):
-    pipeline.__class__ = getattr(pipeline, "_regione_vanilla_class", HS.Step1XEditPipeline)
+    pipeline.__class__ = getattr(pipeline, "_regione_vanilla_class", HS.Step1XEditPipelineV1P2)
     pipeline.scheduler = H.FlowMatchEulerDiscreteScheduler.from_config(pipeline.scheduler.config)
     tr = pipeline.transformer
     if "forward" in tr.__dict__:
@@ -62,7 +64,7 @@ def unwarp_modules(pipeline):
     return pipeline
 
 
-class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
+class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
 
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
@@ -70,40 +72,41 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
                  true_cfg_scale=6.0, guidance_scale=6.0, latents=None, generator=None, output_type="latent",
                  return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4, trace: Optional[dict] = None):
         MANAGER = self._regione_manager
-        assert num_inference_steps == MANAGER.inference_step, "inference step mismatch"
-        do_true_cfg = true_cfg_scale > 1                                     # :230
+        assert num_inference_steps == MANAGER.inference_step, "num_inference_steps must be equal to 28"
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
             image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+        neg_text_ids = torch.zeros(negative_prompt_embeds.shape[1], 3)
         timesteps = self.scheduler.timesteps
-        MANAGER.refresh(latents, image_latents, latent_ids, text_ids, 2, self.vae_scale_factor, height, width)
+        MANAGER.refresh(latents, image_latents, latent_ids, text_ids, neg_text_ids, 2, self.vae_scale_factor, height, width)
         avd, cache = fk.AvdState(), None
         self.scheduler.set_begin_index(0)
         tr = self.transformer
         if hasattr(tr, "set_vec"):
-            tr.set_vec((pooled_prompt_embeds, negative_pooled_prompt_embeds))
-        self._precompute(timesteps, None, latents.dtype, pooled_prompt_embeds,
-                         negative_pooled_prompt_embeds if do_true_cfg else None)
+            tr.set_vec({"cond": pooled_prompt_embeds, "uncond": negative_pooled_prompt_embeds})
+        self._precompute(timesteps, None, latents.dtype, pooled_prompt_embeds, negative_pooled_prompt_embeds)
         for i, t in enumerate(timesteps):
             assert i == MANAGER.current_step
-            should_cache, ratio = fk.avd_decide(MANAGER, avd, i, timesteps, gamma)      # :345-363
-            if should_cache:                                                        # :365-369
+            should_cache, ratio = fk.avd_decide(MANAGER, avd, i, timesteps, gamma)
+            if should_cache:
                 first_hit = cache.shape[1] != latents.shape[1]
                 noise_pred = ops.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
                 if first_hit:
                     cache = ids_gather(cache, MANAGER.edited_ids)
             else:
                 x = latents
-                if MANAGER.is_full_input_step():                                    # :378-379
+                if MANAGER.is_full_input_step():
                     x = torch.cat([latents, image_latents], dim=1)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
-                assert do_true_cfg, "the reference leaves noise_pred undefined without true CFG (:381-399)"
-                xb, pe = self._batched_inputs(x, prompt_embeds, negative_prompt_embeds)
-                timestep = torch.cat((timestep, timestep), dim=0)
-                noise_pred = tr(hidden_states=xb, timestep=timestep / 1000, guidance=None, encoder_hidden_states=pe,
-                                prompt_embeds_mask=None, txt_ids=text_ids, img_ids=latent_ids, return_dict=False)[0]
-                noise_pred = noise_pred[:, : latents.size(1)]
-                noise_pred = self._cfg(noise_pred, t, true_cfg_scale, timesteps_truncate, process_norm_power)
-                cache = noise_pred                                                  # :411
+                pos = tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=prompt_embeds,
+                         prompt_embeds_mask=None, txt_ids=text_ids, img_ids=latent_ids,
+                         joint_attention_kwargs={"tag": "cond"}, return_dict=False)[0][:, : latents.size(1)]      # :388-401
+                neg = tr(hidden_states=x, timestep=timestep / 1000, guidance=None,
+                         encoder_hidden_states=negative_prompt_embeds, prompt_embeds_mask=None, txt_ids=neg_text_ids,
+                         img_ids=latent_ids, joint_attention_kwargs={"tag": "uncond"},
+                         return_dict=False)[0][:, : latents.size(1)]                                                 # :403-419
+                mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN                    # :421
+                noise_pred = ops.cfg_combine(pos, neg, true_cfg_scale, mode, process_norm_power)
+                cache = noise_pred
             if trace is not None:
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))
                 trace.setdefault("noise_pred", []).append(noise_pred.clone())
@@ -111,7 +114,6 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
             latents, latent_ids = MANAGER.step(latents, latent_ids)
             if trace is not None:
                 trace.setdefault("latents", []).append(latents.clone())
-                trace.setdefault("prev_refresh", []).append(MANAGER.prev_refresh_step)
         if not return_dict:
             return (latents,)
         return HS.Step1XEditPipelineOutput(images=latents)
@@ -119,9 +121,11 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
 
 def RegionEStep1XEditTransformer2DModelforward(self, hidden_states, encoder_hidden_states=None, prompt_embeds_mask=None,
                                                timestep=None, img_ids=None, txt_ids=None, guidance=None,
-                                               joint_attention_kwargs=None, return_dict=True):
-    """Step1XEdit/inplace.py:460-578: query RoPE table from the current ids, key table from the full ids."""
+                                               joint_attention_kwargs=None, return_dict=True, text_embeddings=None,
+                                               text_mask=None):
+    """Step1XEditV1P2/inplace.py:546-690."""
     MANAGER = self._regione_manager
     image_rotary_emb = fk.dual_rope_tables(self, MANAGER, txt_ids, img_ids)
-    return self._run_batched(hidden_states, encoder_hidden_states, prompt_embeds_mask, timestep, image_rotary_emb,
-                             return_dict)
+    tag = (joint_attention_kwargs or {}).get("tag", "cond")
+    return self._run(hidden_states, encoder_hidden_states, self._vec[tag], timestep, None, image_rotary_emb, return_dict,
+                     {"tag": tag})

@@ -98,3 +98,34 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
         if not return_dict:
             return (latents,)
         return Step1XEditPipelineOutput(images=latents)
+
+
+class Step1XEditPipelineV1P2(Step1XEditPipeline):
+    """Vanilla v1p2 loop: SEQUENTIAL cond / uncond forwards (Step1XEditV1P2/inplace.py:388-430)."""
+
+    @torch.no_grad()
+    def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
+                 negative_pooled_prompt_embeds=None, height=1024, width=1024, num_inference_steps=28,
+                 true_cfg_scale=6.0, guidance_scale=6.0, latents=None, generator=None, output_type="latent",
+                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4):
+        latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+        neg_text_ids = torch.zeros(negative_prompt_embeds.shape[1], 3)
+        timesteps = self.scheduler.timesteps
+        self.scheduler.set_begin_index(0)
+        tr = self.transformer
+        self._precompute(timesteps, None, latents.dtype, pooled_prompt_embeds, negative_pooled_prompt_embeds)
+        for i, t in enumerate(timesteps):
+            x = torch.cat([latents, image_latents], dim=1)
+            timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            outs = []
+            for pe, y, ids_t, tag in ((prompt_embeds, pooled_prompt_embeds, text_ids, "cond"),
+                                      (negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond")):
+                rope = tr.pos_embed(torch.cat((ids_t, latent_ids), dim=0), tr.device)
+                outs.append(tr._run(x, pe, y, timestep / 1000, None, rope, False, {"tag": tag})[0][:, : latents.size(1)])
+            mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN
+            noise_pred = ops.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+        if not return_dict:
+            return (latents,)
+        return Step1XEditPipelineOutput(images=latents)

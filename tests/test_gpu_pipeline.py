@@ -196,3 +196,44 @@ def test_step1x_toy_mmdit_vs_oracle():
                         neg_model_fn=mk(nprompt, ny), true_cfg_scale=4.0)
     assert torch.equal(pipe._regione_manager.edited_ids.cpu(), st.edited_ids)
     assert O.psnr(out, ref) >= 40.0
+
+
+def test_step1x_v1p2_toy_mmdit_vs_oracle_different_text_lengths():
+    """Sequential tagged CFG with T_cond != T_uncond (per-text-length selection rows / RoPE tables and
+    per-tag K/V caches, Step1XEditV1P2/inplace.py:833,868) on the HIP engine vs the oracle."""
+    from regione_amd.harness import step1x as HS
+    cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
+    h = w = 16
+    Tp, Tn = 32, 24
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+    lat, img, prompt, y = synth.make_edit_inputs(h, w, Tp, cfg, seed=9, dtype=torch.bfloat16)
+    _, _, nprompt, ny = synth.make_edit_inputs(h, w, Tn, cfg, seed=10, dtype=torch.bfloat16)
+    pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.1)
+    helper.enable()
+    out = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=y.cuda(),
+               negative_prompt_embeds=nprompt.cuda(), negative_pooled_prompt_embeds=ny.cuda(), height=h * 16,
+               width=w * 16, latents=lat.cuda(), true_cfg_scale=4.0, return_dict=False)[0].cpu()
+    st = O.RegionState()
+    st.set_parameters(28, 6, 2, "16", 0.1, 0.02, True)
+    ocfg = O.FluxCfg(**synth.TOY)
+
+    def mk(pe, pp, T):
+        caches = [O.KVCache() for _ in range(cfg.n_layers)]
+        def model(x, t, img_ids):
+            st.txt_length = T                                    # txt_length / neg_txt_length of the branch
+            ts = t.expand(x.shape[0]).to(x.dtype)
+            return O.transformer_forward(wts, ocfg, st, caches, x, pe, pp, ts / 1000, img_ids, torch.zeros(T, 3), None)
+        return model
+    with torch.no_grad():
+        ref = O.denoise(mk(prompt, y, Tp), st, lat, img, synth.flux_latent_ids(h, w), Tp, h, w, family="step1x_v1p2",
+                        neg_model_fn=mk(nprompt, ny, Tn), true_cfg_scale=4.0)
+    assert torch.equal(pipe._regione_manager.edited_ids.cpu(), st.edited_ids)
+    assert O.psnr(out, ref) >= 40.0
+    # vanilla v1p2 loop runs too
+    helper.disable()
+    van = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=y.cuda(),
+               negative_prompt_embeds=nprompt.cuda(), negative_pooled_prompt_embeds=ny.cuda(), height=h * 16,
+               width=w * 16, latents=lat.cuda(), true_cfg_scale=4.0, return_dict=False)[0]
+    assert torch.isfinite(van.float()).all()

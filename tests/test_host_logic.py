@@ -201,3 +201,46 @@ def test_step1x_product_loop_matches_reference_trace(golden, cpu_ops, name):
     assert [x.shape[1] for x in trace["latents"]] == g["len"].tolist()
     assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
     assert torch.equal(out, g["final"])
+
+
+class FakeTransformerTagged(FakeTransformerB2):
+    """Sequential-CFG stand-in (Step1X-v1p2): branch = joint_attention_kwargs['tag']."""
+
+    def __call__(self, hidden_states=None, timestep=None, img_ids=None, joint_attention_kwargs=None, **kw):
+        tgt = self.t2[0 if joint_attention_kwargs["tag"] == "cond" else 1]
+        tok = (img_ids[:, 0] * self.L + img_ids[:, 1] * self.w_tok + img_ids[:, 2]).long().to(self.device)
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        return (((hidden_states.float() - tgt[tok[:n]][None]) * k).to(hidden_states.dtype),)
+
+
+def step1x_v1p2_case(g, device="cpu"):
+    from regione_amd.harness import step1x as HS
+    h, w = g["h"], g["w"]
+    dt = torch.bfloat16 if g["bf16"] else torch.float32
+    L = h * w
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=dt)
+    tpos = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    tneg = tpos + 0.05 * torch.randn(tpos.shape, generator=torch.Generator().manual_seed(g["nseed"]))
+    cond = img[0].float()
+    tr = FakeTransformerTagged(torch.cat([tpos, cond], 0), torch.cat([tneg, cond], 0), w, L, device)
+    pipe = HS.Step1XEditPipelineV1P2(tr)
+    helper = RegionEHelper(pipe)
+    assert helper.name == "Step1XEditPipelineV1P2" and helper.config["threshold"] == 0.88
+    helper.enable()
+    trace = {}
+    out = pipe(image=img, prompt_embeds=torch.zeros(1, g["txt_len"], 4).to(dt),
+               negative_prompt_embeds=torch.zeros(1, g["neg_txt_len"], 4).to(dt), height=h * 16, width=w * 16,
+               latents=lat, true_cfg_scale=g["true_cfg_scale"], return_dict=False, trace=trace)[0]
+    return pipe, out, trace
+
+
+def test_step1x_v1p2_product_loop_matches_reference_trace(golden, cpu_ops):
+    g = golden("s1xv2_loop_bf16_32")
+    pipe, out, trace = step1x_v1p2_case(g)
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    M = pipe._regione_manager
+    assert M.txt_length == 8 and M.neg_txt_length == 5
+    assert torch.equal(M.edited_ids.squeeze(0).int(), g["edited_ids"].squeeze(0))
+    assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
+    assert torch.equal(out, g["final"])

@@ -435,6 +435,99 @@ def gen_step1x_loop(ns):
         print("   kinds:", "".join(kinds), " K_e =", ip.MANAGER.edited_ids.shape[1], "/", L)
 
 
+class FakeTransformerTagged:
+    """Sequential-CFG stand-in (Step1X-v1p2 / Qwen): the branch arrives as joint_attention_kwargs['tag']."""
+
+    def __init__(self, tpos_full, tneg_full, w_tok, L):
+        self.config = ref_stubs._Cfg(in_channels=64, guidance_embeds=False)
+        self.transformer_blocks, self.single_transformer_blocks = [], []
+        self.t = {"cond": tpos_full, "uncond": tneg_full}
+        self.w_tok, self.L = w_tok, L
+
+    def __call__(self, hidden_states=None, timestep=None, img_ids=None, joint_attention_kwargs=None, **kw):
+        tgt = self.t[joint_attention_kwargs["tag"]]
+        tok = (img_ids[:, 0] * self.L + img_ids[:, 1] * self.w_tok + img_ids[:, 2]).long()
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        return (((hidden_states.float() - tgt[tok[:n]][None]) * k).to(hidden_states.dtype),)
+
+
+def gen_step1x_v1p2_loop(ns):
+    """Reference RegionEStep1XEditPipeline.__call__ of Step1XEditV1P2 (sequential CFG with tags, per-branch
+    text lengths, norm-rescaled CFG, v1p2 gamma), reflection / thinking disabled."""
+    import diffusers
+    ip = ns.step1x_v1p2
+    for name, h, w, dtype, box in (("s1xv2_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),):
+        fcfg = synth.FluxConfig()
+        latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
+        L = h * w
+        tpos = synth.region_target(h, w, box, image_latents, seed=7, ramp=0.9)
+        tneg = tpos + 0.05 * torch.randn(tpos.shape, generator=torch.Generator().manual_seed(11))
+        cond = image_latents[0].float()
+        tr = FakeTransformerTagged(torch.cat([tpos, cond], 0), torch.cat([tneg, cond], 0), w, L)
+        pipe = diffusers.Step1XEditPipelineV1P2()
+        pipe.scheduler = ref_stubs.FlowMatchEulerDiscreteScheduler()
+        pipe.transformer = tr
+        ids_full = synth.flux_latent_ids(h, w)
+        dummy = torch.zeros(1, 8, 4).to(dtype)
+        pe = ref_stubs._Cfg(embedding=dummy, mask=None, txt_ids=torch.zeros(8, 3), text_embeds=None, text_masks=None)
+        ne = ref_stubs._Cfg(embedding=dummy[:, :5], mask=None, txt_ids=torch.zeros(5, 3), text_embeds=None, text_masks=None)
+        pipe.encode_image = lambda image, width, height, size_level, device, n: (image, None, None, width, height)
+        pipe.encode_prompt = lambda **k: (ne if k.get("prompt") == "" else pe)
+        pipe.prepare_latents = lambda *a, **k: (latents.clone(), image_latents.clone(), ids_full[:L].clone(),
+                                                ids_full[L:].clone())
+        cfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.88,
+                   cache_threshold=0.02, erosion_dilation=True)
+        ip.warp_modules(pipe, **cfg)
+        rec = {k: [] for k in ("noise_pred", "len", "prev_refresh", "latents", "calls")}
+        sch = pipe.scheduler
+        orig_step, orig_mstep = sch.step, ip.MANAGER.step
+
+        def step_hook(model_output, timestep, sample, **kw):
+            rec["noise_pred"].append(model_output.clone())
+            return orig_step(model_output, timestep, sample, **kw)
+
+        def mstep_hook(latent, latent_ids):
+            out = orig_mstep(latent, latent_ids)
+            rec["len"].append(out[0].shape[1])
+            rec["prev_refresh"].append(-1 if ip.MANAGER.prev_refresh_step is None else ip.MANAGER.prev_refresh_step)
+            rec["latents"].append(out[0].clone())
+            return out
+        inner = tr.__class__.__call__
+
+        class _Rec(tr.__class__):
+            def __call__(self, **kw):
+                rec["calls"].append((ip.MANAGER.current_step, kw["hidden_states"].shape[1]))
+                return inner(self, **kw)
+        tr.__class__ = _Rec
+        sch.step, ip.MANAGER.step = step_hook, mstep_hook
+        out = None
+        try:
+            out = pipe(image=torch.zeros(1, 3, 8, 8), prompt="edit", height=h * 16, width=w * 16, num_inference_steps=28,
+                       true_cfg_scale=6.0, guidance_scale=6.0, output_type="latent", return_dict=False,
+                       enable_thinking_mode=False, enable_reflection_mode=False)
+        except RuntimeError as e:
+            # reference quirk: with output_type="latent" the post-loop `if out_images` (Step1XEditV1P2/inplace.py:491)
+            # evaluates a multi-element tensor; the denoise loop itself has completed and is fully recorded.
+            assert "Boolean value of Tensor" in str(e) and len(rec["latents"]) == 28
+        finally:
+            ip.MANAGER.step = orig_mstep
+        called = dict(rec["calls"])
+        kinds = ["C" if i not in called else ("F" if called[i] == 2 * L else "R") for i in range(28)]
+        d = dict(h=h, w=w, box=np.array(box), seed=42, tseed=7, nseed=11, ramp=0.9, bf16=int(dtype == torch.bfloat16),
+                 txt_len=8, neg_txt_len=5,
+                 chk=float(latents.double().sum() + image_latents.double().sum() + tpos.double().sum() + tneg.double().sum()),
+                 kinds=np.array(kinds), len=np.array(rec["len"]), prev_refresh=np.array(rec["prev_refresh"]),
+                 final=rec["latents"][-1], edited_ids=ip.MANAGER.edited_ids.to(torch.int32), threshold=0.88,
+                 cache_threshold=0.02, true_cfg_scale=6.0,
+                 np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+                 lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]))
+        for i in (4, 5, 6, 7, 15, 16, 26):
+            d[f"lat{i}"] = rec["latents"][i]
+        save(name, d)
+        print("   kinds:", "".join(kinds), " K_e =", ip.MANAGER.edited_ids.shape[1], "/", L, " out type", type(out))
+
+
 def gen_toy_cfg(ns):
     """FLUX true-CFG (true_cfg_scale > 1, sequential cond / uncond forwards sharing ONE K/V cache,
     reference quirk A-4) at toy dims."""
@@ -496,6 +589,8 @@ def main():
         gen_toy_cfg(ns)
     if "step1x" in which or not sys.argv[1:]:
         gen_step1x_loop(ns)
+    if "v1p2" in which or not sys.argv[1:]:
+        gen_step1x_v1p2_loop(ns)
 
 
 if __name__ == "__main__":

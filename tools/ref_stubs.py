@@ -491,6 +491,7 @@ def install():
     # Step1X-Edit (v1p1): same trunk; pipeline base needs process_diff_norm [EXT]
     sys.modules["diffusers"].Step1XEditPipeline = type("Step1XEditPipeline", (_FakeStep1XBase,), {})
     sys.modules["diffusers.pipelines.step1x_edit"].Step1XEditPipelineOutput = _BaseOutput
+    sys.modules["diffusers"].Step1XEditPipelineV1P2 = type("Step1XEditPipelineV1P2", (_FakeStep1XBase,), {})
     ts = sys.modules["diffusers.models.transformers.transformer_step1x_edit"]
     ts.Step1XEditAttention = Attention
     ts.Step1XEditAttnProcessor = FluxAttnProcessor
@@ -509,5 +510,8 @@ def install():
     ns.step1x_utils = importlib.import_module("RegionE.Step1XEdit.utils")
     ns.step1x.flash_attn = None
     ns.step1x._partially_linear = partially_linear_cpu
+    ns.step1x_v1p2 = importlib.import_module("RegionE.Step1XEditV1P2.inplace")
+    ns.step1x_v1p2.flash_attn = None
+    ns.step1x_v1p2._partially_linear = partially_linear_cpu
     pkg._ns = ns
     return ns
