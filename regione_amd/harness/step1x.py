@@ -32,7 +32,7 @@ class Step1XEditTransformer2DModel(H.FluxTransformer2DModel):
 
     def set_vec(self, y_rows):
         """Connector output y per batch row (cond, uncond)."""
-        self._vec = list(y_rows)
+        self._vec = dict(y_rows) if isinstance(y_rows, dict) else list(y_rows)
 
     def connector(self, encoder_hidden_states, timestep, prompt_embeds_mask):
         return encoder_hidden_states, self._vec
