@@ -138,6 +138,11 @@ int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bia
 int rgn_gemv_bf16(const void* x, int ldx, const void* W, const void* bias, void* y, int ldy, int B, int N,
                   int K, int silu_input, void* stream);
 
+/* out[m,:] = bf16(bf16(x[m,:] * rsqrt(mean(x^2) + eps)) * w)  - RMSNorm over rows of width d
+ * (QwenImageTransformer2DModel.txt_norm [EXT], call site QwenImageEdit/inplace.py:514). */
+int rgn_rms_norm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int M, int d, float eps,
+                      void* stream);
+
 /* y = bf16(silu(x)) elementwise on bf16 (F.silu of the AdaLN conditioning vector). */
 int rgn_silu_bf16(const void* x, void* y, size_t n, void* stream);
 

@@ -40,6 +40,10 @@ GAMMA = {
     "step1x": [0.9746, 0.9593, 1.0036, 1.0084, 1.0106, 1.0114, 1.0138, 1.0163, 1.0152,
                1.0163, 1.0197, 1.0186, 1.0219, 1.0218, 1.0223, 1.0266, 1.0272, 1.0305,
                1.0311, 1.0362, 1.0385, 1.0423, 1.0500, 1.0536, 1.0671, 1.0866, 1.1015],
+    # QwenImageEdit/inplace.py:47-50
+    "qwen": [1.0195, 1.0233, 1.0243, 1.0185, 1.0321, 1.0208, 1.0260, 1.0233, 1.0258,
+             1.0292, 1.0316, 1.0306, 1.0289, 1.0347, 1.0329, 1.0402, 1.0378, 1.0384,
+             1.0413, 1.0444, 1.0526, 1.0400, 1.0555, 1.0439, 1.0357, 1.0118, 0.7603],
     # Step1XEditV1P2/inplace.py:48-50
     "step1x_v1p2": [0.7936, 0.9807, 1.0063, 1.0205, 0.9946, 1.0125, 1.0116, 1.0125, 1.0172,
                     1.0171, 1.0183, 1.0170, 1.0170, 1.0236, 1.0263, 1.0264, 1.0277, 1.0321,
@@ -392,6 +396,9 @@ def _mlp_embed(w, name, x):
 def time_text_embed(w, timestep, guidance, pooled):
     """[EXT] CombinedTimestepGuidanceTextProjEmbeddings."""
     p = "time_text_embed."
+    if pooled is None:       # Qwen-Image: conditioning = timestep embedding only [EXT QwenTimestepProjEmbeddings]
+        dt = w[p + "timestep_embedder.linear_1.weight"].dtype
+        return _mlp_embed(w, p + "timestep_embedder", timestep_embedding(timestep).to(dt))
     t = _mlp_embed(w, p + "timestep_embedder", timestep_embedding(timestep).to(pooled.dtype))
     if guidance is None:     # Step1X-Edit: temb = time_embed(t) + vec_embed(y)  (Step1XEdit/inplace.py:519-520)
         return t + _mlp_embed(w, p + "text_embedder", pooled)
@@ -502,16 +509,43 @@ class FluxCfg:
         return self.heads * self.head_dim
 
 
+def qwen_rope(img_shapes, txt_len, axes_dim=(16, 56, 56), theta=10000.0):
+    """[EXT] QwenEmbedRope(scale_rope=True): (cos, sin) fp32 [txt_len + sum(f*h*w), 128], text rows first
+    (text positions start after the image extent; image axes are centred)."""
+    def params(index, dim):
+        return torch.outer(index.float(), 1.0 / torch.pow(theta, torch.arange(0, dim, 2).float().div(dim)))
+    pos_i, neg_i = torch.arange(4096), torch.arange(4096).flip(0) * -1 - 1
+    pos, neg = [params(pos_i, d) for d in axes_dim], [params(neg_i, d) for d in axes_dim]
+    ang, max_vid = [], 0
+    for idx, (fr, h, w) in enumerate(img_shapes):
+        f = pos[0][idx: idx + fr].view(fr, 1, 1, -1).expand(fr, h, w, -1)
+        hh = torch.cat([neg[1][-(h - h // 2):], pos[1][: h // 2]], 0).view(1, h, 1, -1).expand(fr, h, w, -1)
+        ww = torch.cat([neg[2][-(w - w // 2):], pos[2][: w // 2]], 0).view(1, 1, w, -1).expand(fr, h, w, -1)
+        ang.append(torch.cat([f, hh, ww], -1).reshape(fr * h * w, -1))
+        max_vid = max(max_vid, h // 2, w // 2)
+    a = torch.cat([torch.cat([p[max_vid: max_vid + txt_len] for p in pos], 1)] + ang, 0)
+    return a.cos().repeat_interleave(2, dim=1), a.sin().repeat_interleave(2, dim=1)
+
+
 def transformer_forward(w, cfg: FluxCfg, st: RegionState, caches: List[KVCache], hidden, enc, pooled,
-                        timestep, img_ids, txt_ids, guidance, fp16_roundtrip=True):
-    """inplace.py:413-576.  `timestep` arrives already divided by 1000 (inplace.py:336)."""
+                        timestep, img_ids, txt_ids, guidance, fp16_roundtrip=True, rope_full=None):
+    """inplace.py:413-576.  `timestep` arrives already divided by 1000 (inplace.py:336).
+    rope_full: precomputed (cos, sin) for [text ; FULL latent ids] (Qwen: 1-D ids index its image rows,
+    QwenImageEdit/inplace.py:531); the query table is its rows at [text ; current ids]."""
+    if "txt_norm.weight" in w:                       # [EXT] QwenImageTransformer2DModel.txt_norm
+        enc = rms_norm(enc, w["txt_norm.weight"])
     h = _lin(w, "x_embedder", hidden)
     ts = timestep.to(h.dtype) * 1000
     g = guidance.to(h.dtype) * 1000 if guidance is not None else None
     temb = time_text_embed(w, ts, g, pooled)
     c = _lin(w, "context_embedder", enc)
-    rope_q = flux_pos_embed(torch.cat((txt_ids, img_ids), 0), cfg.axes_dim)            # :495-496
-    rope_k = flux_pos_embed(torch.cat((txt_ids, st.latent_ids), 0), cfg.axes_dim)      # :499
+    if rope_full is not None:
+        T = enc.shape[1]
+        sel = torch.cat((torch.arange(T), T + img_ids.long()))
+        rope_q, rope_k = (rope_full[0][sel], rope_full[1][sel]), rope_full
+    else:
+        rope_q = flux_pos_embed(torch.cat((txt_ids, img_ids), 0), cfg.axes_dim)            # :495-496
+        rope_k = flux_pos_embed(torch.cat((txt_ids, st.latent_ids), 0), cfg.axes_dim)      # :499
     li = 0
     for i in range(cfg.n_double):
         c, h = double_block(w, f"transformer_blocks.{i}", cfg.heads, st, caches[li], h, c, temb, rope_q, rope_k,

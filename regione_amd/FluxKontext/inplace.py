@@ -167,13 +167,14 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
         return H.FluxPipelineOutput(images=latents)
 
 
-def dual_rope_tables(transformer, MANAGER, txt_ids, img_ids):
+def dual_rope_tables(transformer, MANAGER, txt_ids, img_ids, build_full=None):
     """Query-row rotary table for this forward; also makes sure the FULL-id key table of this text
-    length exists (MANAGER.image_rotary_emb of the reference, inplace.py:495-500)."""
-    T = txt_ids.shape[0]
+    length exists (MANAGER.image_rotary_emb of the reference, inplace.py:495-500).  `build_full(T)`
+    overrides the FLUX table builder (Qwen: QwenImageEdit/inplace.py:531)."""
+    T = txt_ids.shape[0] if hasattr(txt_ids, "shape") else int(txt_ids)
     if T not in MANAGER.rope_full_by_T:
-        MANAGER.rope_full_by_T[T] = transformer.pos_embed(torch.cat((txt_ids.cpu(), MANAGER.latent_ids.cpu()), dim=0),
-                                                         transformer.device)
+        MANAGER.rope_full_by_T[T] = build_full(T) if build_full is not None else transformer.pos_embed(
+            torch.cat((txt_ids.cpu(), MANAGER.latent_ids.cpu()), dim=0), transformer.device)
     full = MANAGER.rope_full_by_T[T]
     if MANAGER.image_rotary_emb is None:
         MANAGER.image_rotary_emb = full

@@ -159,6 +159,23 @@ __global__ __launch_bounds__(256) void v_transpose_store_kernel(const uint16_t* 
     }
 }
 
+// Row RMSNorm with affine weight (Qwen `txt_norm` on the prompt embeddings, [EXT] RMSNorm semantics:
+// fp32 variance, x*rsqrt in fp32, round to bf16, times bf16 weight).
+__global__ __launch_bounds__(256) void rms_norm_rows_kernel(const uint16_t* __restrict__ x, int ldx,
+                                                            const uint16_t* __restrict__ w, uint16_t* __restrict__ out,
+                                                            int ldo, int d, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t* xr = x + (size_t)row * ldx;
+    float s = 0.f;
+    for (int i = tid; i < d; i += 256) { const float v = bf2f(xr[i]); s += v * v; }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float r = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + eps);
+    for (int i = tid; i < d; i += 256) out[(size_t)row * ldo + i] = f2bf(rbf(bf2f(xr[i]) * r) * bf2f(w[i]));
+}
+
 __global__ void silu_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = bf2f(x[i]);
@@ -182,6 +199,14 @@ int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, fl
                        (uint16_t*)out, ldo, d, eps, split_row, (const uint16_t*)shift0, (const uint16_t*)scale0,
                        (const uint16_t*)shift1, (const uint16_t*)scale1);
     return check_launch("ln_modulate_kernel");
+}
+
+int rgn_rms_norm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int M, int d, float eps, void* stream) {
+    if (M == 0) return 0;
+    if (!x || !w || !out || M < 0 || d <= 0) return fail(RGN_E_BADARG, "rms_norm_rows: bad argument");
+    hipLaunchKernelGGL(rms_norm_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+                       (const uint16_t*)w, (uint16_t*)out, ldo, d, eps);
+    return check_launch("rms_norm_rows_kernel");
 }
 
 int rgn_silu_bf16(const void* x, void* y, size_t n, void* stream) {

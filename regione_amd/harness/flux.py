@@ -381,6 +381,8 @@ class FluxTransformer2DModel:
                 mod_w[self.mo_out:self.mo_out + 2 * d] = take("norm_out.linear.weight")
             if "norm_out.linear.bias" in pend:
                 mod_b[self.mo_out:self.mo_out + 2 * d] = take("norm_out.linear.bias")
+            if "txt_norm.weight" in pend:
+                self.txt_norm_weight = take("txt_norm.weight").contiguous()
             for n in ("x_embedder", "context_embedder", "proj_out"):
                 for s in ("weight", "bias"):
                     if f"{n}.{s}" in pend:
@@ -414,7 +416,10 @@ class FluxTransformer2DModel:
             return ops.gemv(h, getattr(self, f"tte_{e}_linear_2_weight"), getattr(self, f"tte_{e}_linear_2_bias"),
                             silu_input=True)
         te = timestep_embedding(timestep.detach().float().cpu()).to(torch.bfloat16).to(self.device)
-        t, p = mlp("timestep_embedder", te), mlp("text_embedder", pooled)
+        t = mlp("timestep_embedder", te)
+        if not self.cfg_model.pooled_embeds or pooled is None:
+            return t              # Qwen-Image: conditioning = timestep embedding only
+        p = mlp("text_embedder", pooled)
         if not self.cfg_model.guidance_embeds or guidance is None:
             return t + p          # Step1X-Edit: temb = time_embed(t) + vec_embed(y)
         ge = timestep_embedding(guidance.detach().float().cpu()).to(torch.bfloat16).to(self.device)
@@ -442,14 +447,14 @@ class FluxTransformer2DModel:
         ops.gemm(ops.silu(temb), self.mod_w, self.mod_b, table)
         if not hasattr(self, "_mod_tables") or len(self._mod_tables) > 4:
             self._mod_tables = {}
-        self._mod_tables[pooled.data_ptr()] = dict(keys={k: i for i, k in enumerate(keys)}, table=table,
+        self._mod_tables[0 if pooled is None else pooled.data_ptr()] = dict(keys={k: i for i, k in enumerate(keys)}, table=table,
                                                    guidance=None if gd is None else float(gd[0]))
 
     def clear_modulations(self):
         self._mod_tables = {}
 
     def _lookup_modulation(self, ts, gd, pooled) -> Optional[Modulation]:
-        mt = getattr(self, "_mod_tables", {}).get(pooled.data_ptr())
+        mt = getattr(self, "_mod_tables", {}).get(0 if pooled is None else pooled.data_ptr())
         if mt is None or mt["guidance"] != (None if gd is None else float(gd[0])):
             return None
         i = mt["keys"].get(float(ts[0]))
@@ -475,7 +480,10 @@ class FluxTransformer2DModel:
         ws.ensure(R, R)
         d = self.cfg_model.d
         ops.gemm(hidden_states[0], self.x_embedder_weight, self.x_embedder_bias, ws.x[T:R])
-        ops.gemm(encoder_hidden_states[0], self.context_embedder_weight, self.context_embedder_bias, ws.x[:T])
+        enc = encoder_hidden_states[0]
+        if self.cfg_model.txt_norm:
+            enc = ops.rms_norm_rows(enc, self.txt_norm_weight)
+        ops.gemm(enc, self.context_embedder_weight, self.context_embedder_bias, ws.x[:T])
         ts = timestep.to(torch.bfloat16) * 1000                       # inplace.py:471
         gd = guidance.to(torch.bfloat16) * 1000 if guidance is not None else None
         mods = self._lookup_modulation(ts, gd, pooled)
@@ -548,8 +556,8 @@ class FluxKontextPipeline:
     def _precompute(self, timesteps, guidance, dtype, *pooled_list):
         if hasattr(self.transformer, "precompute_modulations"):
             self.transformer.clear_modulations()
-            for pooled in pooled_list:
-                if pooled is not None:
+            for pooled in (pooled_list or (None,)):
+                if pooled is not None or not self.transformer.cfg_model.pooled_embeds:
                     self.transformer.precompute_modulations([t.expand(1).to(dtype) / 1000 for t in timesteps], guidance, pooled)
 
     @torch.no_grad()

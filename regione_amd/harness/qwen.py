@@ -1,0 +1,143 @@
+"""Qwen-Image-Edit-shaped harness on the HIP engine.
+
+[EXT] QwenImageTransformer2DModel = 60 double-stream MMDiT blocks (img_mod/txt_mod = SiLU + Linear(d, 6d),
+LayerNorm without affine, joint attention with RMSNorm on q/k of both streams, GELU-tanh FeedForward) -
+chunk order (shift, scale, gate) x 2 is the same as FLUX's AdaLN-Zero, so the FLUX double-block launch
+plan is reused with n_single = 0.  Differences handled here:
+  * conditioning = timestep embedding only (no pooled / guidance embedder);
+  * `txt_norm` (RMSNorm over the 3584-wide prompt embeddings) before the text projection;
+  * rotary table: QwenEmbedRope (complex, 3 axes 16/56/56, centred positions, text after the image
+    extent) - applying complex freqs to (x[2i], x[2i+1]) pairs is the same rotation as FLUX's real
+    interleaved form, so the kernels consume a (cos, sin) table built on the host here;
+  * latent ids are 1-D (`arange`, QwenImageEdit/inplace.py:322);
+  * CFG is sequential with 'cond' / 'uncond' tags and norm-preserving (QwenImageEdit/inplace.py:371-405).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..synth import FluxConfig
+from . import flux as H
+
+
+def _rope_params(index: torch.Tensor, dim: int, theta: float = 10000.0) -> torch.Tensor:
+    """[EXT] QwenEmbedRope.rope_params -> angles [len(index), dim/2] (fp32 like the module's float32 path)."""
+    return torch.outer(index.float(), 1.0 / torch.pow(theta, torch.arange(0, dim, 2).float().div(dim)))
+
+
+class QwenEmbedRope:
+    """[EXT] diffusers QwenEmbedRope(theta=10000, axes_dim=(16,56,56), scale_rope=True), restated on the host."""
+
+    def __init__(self, theta=10000, axes_dim=(16, 56, 56), scale_rope=True):
+        self.theta, self.axes_dim, self.scale_rope = theta, tuple(axes_dim), scale_rope
+        pos_index = torch.arange(4096)
+        neg_index = torch.arange(4096).flip(0) * -1 - 1
+        self.pos = [_rope_params(pos_index, d, theta) for d in self.axes_dim]
+        self.neg = [_rope_params(neg_index, d, theta) for d in self.axes_dim]
+
+    def video_angles(self, frame, height, width, idx):
+        f = self.pos[0][idx: idx + frame].view(frame, 1, 1, -1).expand(frame, height, width, -1)
+        if self.scale_rope:
+            hh = torch.cat([self.neg[1][-(height - height // 2):], self.pos[1][: height // 2]], dim=0)
+            ww = torch.cat([self.neg[2][-(width - width // 2):], self.pos[2][: width // 2]], dim=0)
+        else:
+            hh, ww = self.pos[1][:height], self.pos[2][:width]
+        hh = hh.view(1, height, 1, -1).expand(frame, height, width, -1)
+        ww = ww.view(1, 1, width, -1).expand(frame, height, width, -1)
+        return torch.cat([f, hh, ww], dim=-1).reshape(frame * height * width, -1)
+
+    def __call__(self, img_shapes, txt_len: int, device="cuda"):
+        """img_shapes: [(frame, h, w), ...] -> (cos, sin) fp32 [txt_len + sum(f*h*w), 128], text rows first."""
+        ang, max_vid = [], 0
+        for idx, (fr, h, w) in enumerate(img_shapes):
+            ang.append(self.video_angles(fr, h, w, idx))
+            max_vid = max(max_vid, h // 2, w // 2) if self.scale_rope else max(max_vid, h, w)
+        txt = torch.cat([p[max_vid: max_vid + txt_len] for p in self.pos], dim=1)
+        a = torch.cat([txt] + ang, dim=0)                                  # [T + N, 64] angles
+        cos = a.cos().repeat_interleave(2, dim=1).contiguous().to(device)
+        sin = a.sin().repeat_interleave(2, dim=1).contiguous().to(device)
+        return cos, sin
+
+
+class QwenDoubleStreamAttnProcessor2_0(H.FluxAttnProcessor):
+    def __init__(self):
+        super().__init__(False)
+
+
+class QwenImageTransformer2DModel(H.FluxTransformer2DModel):
+    def __init__(self, cfg: FluxConfig, device="cuda"):
+        assert cfg.n_single == 0 and not cfg.pooled_embeds and not cfg.guidance_embeds
+        super().__init__(cfg, device)
+        self.pos_embed = QwenEmbedRope(10000, cfg.axes_dim, True)
+
+    def full_rope(self, img_shapes, T):
+        key = (tuple(tuple(s) for s in img_shapes), T)
+        cache = self.__dict__.setdefault("_rope_cache", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = self.pos_embed(img_shapes, T, self.device)
+        return cache[key]
+
+    def forward(self, hidden_states, encoder_hidden_states=None, encoder_hidden_states_mask=None, timestep=None,
+                img_shapes=None, txt_seq_lens=None, guidance=None, attention_kwargs=None, latent_ids=None,
+                return_dict=True):
+        T = encoder_hidden_states.shape[1]
+        rope = self.full_rope(img_shapes[0], T)
+        return self._run(hidden_states, encoder_hidden_states, None, timestep, None, rope, return_dict, attention_kwargs)
+
+    def cache_context(self, name):
+        from contextlib import nullcontext
+        return nullcontext()
+
+
+class QwenImagePipelineOutput(H._Cfg):
+    pass
+
+
+class QwenImageEditPipeline(H.FluxKontextPipeline):
+    """Vanilla loop: sequential cond / uncond forwards + norm-preserving CFG (inplace.py:371-405)."""
+
+    def _shapes(self, height, width):
+        s = (1, height // self.vae_scale_factor // 2, width // self.vae_scale_factor // 2)
+        return [[s, s]]
+
+    def prepare_qwen(self, image, height, width, latents, generator, num_inference_steps):
+        dummy = torch.zeros(1, 1, 1)
+        latents, image_latents, _, _, h_tok, w_tok = self.prepare(image, dummy, None, height, width, latents, generator,
+                                                                  num_inference_steps)
+        latent_ids = torch.arange(latents.shape[1] + image_latents.shape[1])           # :322
+        return latents, image_latents, latent_ids
+
+    @torch.no_grad()
+    def __call__(self, image=None, prompt_embeds=None, negative_prompt_embeds=None, height=1024, width=1024,
+                 num_inference_steps=28, true_cfg_scale=4.0, latents=None, generator=None, output_type="latent",
+                 return_dict=True):
+        latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps)
+        timesteps = self.scheduler.timesteps
+        img_shapes = self._shapes(height, width)
+        do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None
+        self.scheduler.set_begin_index(0)
+        self._precompute(timesteps, None, latents.dtype)
+        tr = self.transformer
+        for i, t in enumerate(timesteps):
+            x = torch.cat([latents, image_latents], dim=1)
+            timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            noise_pred = tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=prompt_embeds,
+                            img_shapes=img_shapes, latent_ids=latent_ids, attention_kwargs={"tag": "cond"},
+                            return_dict=False)[0][:, : latents.size(1)]
+            if do_true_cfg:
+                neg = tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=negative_prompt_embeds,
+                         img_shapes=img_shapes, latent_ids=latent_ids, attention_kwargs={"tag": "uncond"},
+                         return_dict=False)[0][:, : latents.size(1)]
+                noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
+            latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+        if not return_dict:
+            return (latents,)
+        return QwenImagePipelineOutput(images=latents)
+
+
+class QwenImageEditPlusPipeline(QwenImageEditPipeline):
+    """Qwen-Image-Edit-2509: same kernels; multi-image conditioning is list handling in front of the hot
+    path (QwenImageEditPlus/inplace.py:229-299) - the harness takes the concatenated condition latents."""

@@ -207,6 +207,14 @@ def gemv(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], silu_in
     return out
 
 
+def rms_norm_rows(x: torch.Tensor, w: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    out = torch.empty_like(x)
+    rc = _lib.lib().rgn_rms_norm_rows(_p(x), x.stride(0), _p(w), _p(out), out.stride(0), x.shape[0], x.shape[1], eps,
+                                      _stream())
+    _lib.check(rc, "rgn_rms_norm_rows")
+    return out
+
+
 def silu(x: torch.Tensor) -> torch.Tensor:
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     y = torch.empty_like(x)

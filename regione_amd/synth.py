@@ -25,6 +25,8 @@ class FluxConfig:
     axes_dim: Tuple[int, ...] = (16, 56, 56)
     mlp_ratio: int = 4
     guidance_embeds: bool = True          # False: Step1X-Edit style temb = time_embed + vec_embed(y)
+    pooled_embeds: bool = True            # False: Qwen-Image style temb = timestep embedding only
+    txt_norm: bool = False                # True: RMSNorm on the prompt embeddings before the text projection (Qwen)
 
     @property
     def d(self) -> int:
@@ -36,6 +38,11 @@ class FluxConfig:
 
 
 TOY = dict(n_double=2, n_single=2, heads=2, head_dim=128, joint_dim=256, pooled_dim=64)
+# Qwen-Image-Edit [EXT public config]: 60 double-stream blocks only, text width 3584, no pooled / guidance embedders
+QWEN = dict(n_double=60, n_single=0, heads=24, head_dim=128, joint_dim=3584, guidance_embeds=False, pooled_embeds=False,
+            txt_norm=True)
+QWEN_TOY = dict(n_double=3, n_single=0, heads=2, head_dim=128, joint_dim=256, guidance_embeds=False, pooled_embeds=False,
+                txt_norm=True)
 
 
 def flux_param_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
@@ -50,6 +57,8 @@ def flux_param_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
     lin("context_embedder", d, cfg.joint_dim)
     for e, din in (("timestep_embedder", 256), ("guidance_embedder", 256), ("text_embedder", cfg.pooled_dim)):
         if e == "guidance_embedder" and not cfg.guidance_embeds:
+            continue
+        if e == "text_embedder" and not cfg.pooled_embeds:
             continue
         lin(f"time_text_embed.{e}.linear_1", d, din)
         lin(f"time_text_embed.{e}.linear_2", d, d)
@@ -73,6 +82,8 @@ def flux_param_shapes(cfg: FluxConfig) -> Dict[str, Tuple[int, ...]]:
             lin(p + ".attn." + n, d, d)
         for n in ("norm_q", "norm_k"):
             s[p + f".attn.{n}.weight"] = (cfg.head_dim,)
+    if cfg.txt_norm:
+        s["txt_norm.weight"] = (cfg.joint_dim,)
     lin("norm_out.linear", 2 * d, d)
     lin("proj_out", cfg.in_channels, d)
     return s

@@ -237,3 +237,53 @@ def test_step1x_v1p2_toy_mmdit_vs_oracle_different_text_lengths():
                negative_prompt_embeds=nprompt.cuda(), negative_pooled_prompt_embeds=ny.cuda(), height=h * 16,
                width=w * 16, latents=lat.cuda(), true_cfg_scale=4.0, return_dict=False)[0]
     assert torch.isfinite(van.float()).all()
+
+
+def test_qwen_toy_mmdit_vs_oracle():
+    """Qwen-Image-Edit-shaped engine (double-stream only, txt_norm, timestep-only conditioning, Qwen rotary
+    table, sequential tagged CFG with different text lengths, norm-preserving CFG) vs the oracle."""
+    from regione_amd.harness import qwen as HQ
+    cfg = synth.FluxConfig(**synth.QWEN_TOY)
+    h = w = 16
+    Tp, Tn = 32, 24
+    wts = synth.make_flux_weights(cfg, seed=6, dtype=torch.bfloat16, w_std=0.05)
+    lat, img, prompt, _ = synth.make_edit_inputs(h, w, Tp, cfg, seed=9, dtype=torch.bfloat16)
+    _, _, nprompt, _ = synth.make_edit_inputs(h, w, Tn, cfg, seed=10, dtype=torch.bfloat16)
+    pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.1)
+    helper.enable()
+    out = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), negative_prompt_embeds=nprompt.cuda(), height=h * 16,
+               width=w * 16, latents=lat.cuda(), true_cfg_scale=4.0, return_dict=False)[0].cpu()
+    st = O.RegionState()
+    st.set_parameters(28, 6, 2, "16", 0.1, 0.03, True)
+    ocfg = O.FluxCfg(n_double=cfg.n_double, n_single=0, heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim)
+    shapes = [(1, h, w), (1, h, w)]
+
+    def mk(pe, T):
+        caches = [O.KVCache() for _ in range(cfg.n_layers)]
+        rope = O.qwen_rope(shapes, T)
+        def model(x, t, ids):
+            st.txt_length = T
+            ts = t.expand(x.shape[0]).to(x.dtype)
+            return O.transformer_forward(wts, ocfg, st, caches, x, pe, None, ts / 1000, ids, None, None, rope_full=rope)
+        return model
+    with torch.no_grad():
+        ref = O.denoise(mk(prompt, Tp), st, lat, img, torch.arange(2 * h * w), Tp, h, w, family="qwen",
+                        neg_model_fn=mk(nprompt, Tn), true_cfg_scale=4.0)
+    assert torch.equal(pipe._regione_manager.edited_ids.cpu(), st.edited_ids)
+    assert O.psnr(out, ref) >= 40.0
+    helper.disable()
+    van = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), negative_prompt_embeds=nprompt.cuda(), height=h * 16,
+               width=w * 16, latents=lat.cuda(), true_cfg_scale=4.0, return_dict=False)[0]
+    assert torch.isfinite(van.float()).all()
+
+
+@pytest.mark.parametrize("name", ["qwen_loop_bf16_32", "qwen_loop_f32_16"])
+def test_qwen_loop_fixture_on_gpu(golden, name):
+    from tests.test_host_logic import qwen_case
+    g = golden(name)
+    pipe, out, trace = qwen_case(g, device="cuda")
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    assert torch.equal(pipe._regione_manager.edited_ids.cpu().squeeze(0).int(), g["edited_ids"].squeeze(0))
+    assert O.psnr(out.cpu(), g["final"]) > (50.0 if g["bf16"] else 110.0)      # row-norm reduction order (CFG mode 2)

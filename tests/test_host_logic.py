@@ -244,3 +244,56 @@ def test_step1x_v1p2_product_loop_matches_reference_trace(golden, cpu_ops):
     assert torch.equal(M.edited_ids.squeeze(0).int(), g["edited_ids"].squeeze(0))
     assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
     assert torch.equal(out, g["final"])
+
+
+class FakeTransformerQwen(FakeTransformerB2):
+    """Qwen stand-in: 1-D latent ids, branch = attention_kwargs['tag']."""
+
+    def __init__(self, tpos_full, tneg_full, device="cpu"):
+        super().__init__(tpos_full, tneg_full, 1, 1, device)
+        self.cfg_model = synth.FluxConfig(**synth.QWEN_TOY)
+
+    def __call__(self, hidden_states=None, timestep=None, latent_ids=None, attention_kwargs=None, **kw):
+        tgt = self.t2[0 if attention_kwargs["tag"] == "cond" else 1]
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        return (((hidden_states.float() - tgt[latent_ids[:n].long().to(self.device)][None]) * k).to(hidden_states.dtype),)
+
+
+def qwen_case(g, device="cpu", plus=False):
+    from regione_amd.harness import qwen as HQ
+    h, w = g["h"], g["w"]
+    dt = torch.bfloat16 if g["bf16"] else torch.float32
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=dt)
+    tpos = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    tneg = tpos + 0.05 * torch.randn(tpos.shape, generator=torch.Generator().manual_seed(g["nseed"]))
+    cond = img[0].float()
+    tr = FakeTransformerQwen(torch.cat([tpos, cond], 0), torch.cat([tneg, cond], 0), device)
+    pipe = (HQ.QwenImageEditPlusPipeline if plus else HQ.QwenImageEditPipeline)(tr)
+    helper = RegionEHelper(pipe)
+    assert helper.config["threshold"] == 0.80 and helper.config["cache_threshold"] == 0.03      # tool/RegionE.py:5-6
+    helper.enable()
+    trace = {}
+    out = pipe(image=img, prompt_embeds=torch.zeros(1, g["txt_len"], 4).to(dt),
+               negative_prompt_embeds=torch.zeros(1, g["neg_txt_len"], 4).to(dt), height=h * 16, width=w * 16,
+               latents=lat, true_cfg_scale=g["true_cfg_scale"], return_dict=False, trace=trace)[0]
+    return pipe, out, trace
+
+
+@pytest.mark.parametrize("name", ["qwen_loop_bf16_32", "qwen_loop_f32_16"])
+def test_qwen_product_loop_matches_reference_trace(golden, cpu_ops, name):
+    g = golden(name)
+    pipe, out, trace = qwen_case(g)
+    assert pipe.__class__.__name__ == "RegionEQwenImageEditPipeline"
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    assert torch.equal(pipe._regione_manager.edited_ids.squeeze(0).int(), g["edited_ids"].squeeze(0))
+    assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
+    assert torch.equal(out, g["final"])
+
+
+def test_qwen_plus_dispatch_and_gamma(golden, cpu_ops):
+    from regione_amd.QwenImageEditPlus import inplace as qp
+    pipe, out, trace = qwen_case(golden("qwen_loop_f32_16"), plus=True)
+    assert pipe.__class__.__name__ == "RegionEQwenImageEditPlusPipeline"
+    assert float(pipe.gamma[0]) == float(qp.gamma[0]) != float(pipe.__class__.__mro__[1].gamma[0])
+    assert torch.isfinite(out).all()

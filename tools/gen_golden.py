@@ -528,6 +528,93 @@ def gen_step1x_v1p2_loop(ns):
         print("   kinds:", "".join(kinds), " K_e =", ip.MANAGER.edited_ids.shape[1], "/", L, " out type", type(out))
 
 
+class FakeTransformerQwen:
+    """Qwen stand-in: 1-D `latent_ids`, branch in attention_kwargs['tag'], cache_context() manager."""
+
+    def __init__(self, tpos_full, tneg_full):
+        self.config = ref_stubs._Cfg(in_channels=64, guidance_embeds=False)
+        self.transformer_blocks = []
+        self.t = {"cond": tpos_full, "uncond": tneg_full}
+
+    def cache_context(self, name):
+        from contextlib import nullcontext
+        return nullcontext()
+
+    def __call__(self, hidden_states=None, timestep=None, latent_ids=None, attention_kwargs=None, **kw):
+        tgt = self.t[attention_kwargs["tag"]]
+        n = hidden_states.shape[1]
+        k = float(1.0 / timestep.float()[0].item())
+        return (((hidden_states.float() - tgt[latent_ids[:n].long()][None]) * k).to(hidden_states.dtype),)
+
+
+def gen_qwen_loop(ns):
+    """Reference RegionEQwenImageEditPipeline.__call__ (sequential tagged CFG, norm-preserving CFG,
+    Qwen gamma, 1-D latent ids) with the elementwise fake transformer."""
+    import diffusers
+    ip = ns.qwen
+    for name, h, w, dtype, box in (("qwen_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),
+                                   ("qwen_loop_f32_16", 16, 16, torch.float32, (4, 11, 4, 11))):
+        fcfg = synth.FluxConfig()
+        latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
+        L = h * w
+        tpos = synth.region_target(h, w, box, image_latents, seed=7, ramp=0.9)
+        tneg = tpos + 0.05 * torch.randn(tpos.shape, generator=torch.Generator().manual_seed(11))
+        cond = image_latents[0].float()
+        tr = FakeTransformerQwen(torch.cat([tpos, cond], 0), torch.cat([tneg, cond], 0))
+        pipe = diffusers.QwenImageEditPipeline()
+        pipe.scheduler = ref_stubs.FlowMatchEulerDiscreteScheduler()
+        pipe.transformer = tr
+        dummy = torch.zeros(1, 8, 4).to(dtype)
+        pipe.image_processor = ref_stubs._Cfg(resize=lambda im, hh, ww: im,
+                                              preprocess=lambda im, hh, ww: torch.zeros(1, 3, hh, ww))
+        pipe.encode_prompt = lambda **k: ((dummy[:, :5], torch.ones(1, 5)) if k.get("prompt") == " " else (dummy, torch.ones(1, 8)))
+        pipe.prepare_latents = lambda *a, **k: (latents.clone(), image_latents.clone())
+        cfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.80,
+                   cache_threshold=0.03, erosion_dilation=True)
+        ip.warp_modules(pipe, **cfg)
+        rec = {k: [] for k in ("noise_pred", "len", "latents", "calls")}
+        sch = pipe.scheduler
+        orig_step, orig_mstep = sch.step, ip.MANAGER.step
+
+        def step_hook(model_output, timestep, sample, **kw):
+            rec["noise_pred"].append(model_output.clone())
+            return orig_step(model_output, timestep, sample, **kw)
+
+        def mstep_hook(latent, latent_ids):
+            out = orig_mstep(latent, latent_ids)
+            rec["len"].append(out[0].shape[1])
+            rec["latents"].append(out[0].clone())
+            return out
+        inner = tr.__class__.__call__
+
+        class _Rec(tr.__class__):
+            def __call__(self, **kw):
+                rec["calls"].append((ip.MANAGER.current_step, kw["hidden_states"].shape[1]))
+                return inner(self, **kw)
+        tr.__class__ = _Rec
+        sch.step, ip.MANAGER.step = step_hook, mstep_hook
+        img = ref_stubs._Cfg(size=(w * 16, h * 16))
+        try:
+            out = pipe(image=img, prompt="edit", negative_prompt=" ", height=h * 16, width=w * 16,
+                       num_inference_steps=28, true_cfg_scale=4.0, output_type="latent", return_dict=False)
+        finally:
+            ip.MANAGER.step = orig_mstep
+        called = dict(rec["calls"])
+        kinds = ["C" if i not in called else ("F" if called[i] == 2 * L else "R") for i in range(28)]
+        d = dict(h=h, w=w, box=np.array(box), seed=42, tseed=7, nseed=11, ramp=0.9, bf16=int(dtype == torch.bfloat16),
+                 txt_len=8, neg_txt_len=5,
+                 chk=float(latents.double().sum() + image_latents.double().sum() + tpos.double().sum() + tneg.double().sum()),
+                 kinds=np.array(kinds), len=np.array(rec["len"]), final=out[0],
+                 edited_ids=ip.MANAGER.edited_ids.to(torch.int32), threshold=0.80, cache_threshold=0.03,
+                 true_cfg_scale=4.0,
+                 np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+                 lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]))
+        for i in (4, 5, 6, 7, 15, 16, 26):
+            d[f"lat{i}"] = rec["latents"][i]
+        save(name, d)
+        print("   kinds:", "".join(kinds), " K_e =", ip.MANAGER.edited_ids.shape[1], "/", L)
+
+
 def gen_toy_cfg(ns):
     """FLUX true-CFG (true_cfg_scale > 1, sequential cond / uncond forwards sharing ONE K/V cache,
     reference quirk A-4) at toy dims."""
@@ -589,6 +676,8 @@ def main():
         gen_toy_cfg(ns)
     if "step1x" in which or not sys.argv[1:]:
         gen_step1x_loop(ns)
+    if "qwen" in which or not sys.argv[1:]:
+        gen_qwen_loop(ns)
     if "v1p2" in which or not sys.argv[1:]:
         gen_step1x_v1p2_loop(ns)
 

@@ -414,6 +414,23 @@ class _FakePipelineBase:
         yield _PB()
 
 
+def apply_rotary_emb_qwen(x, freqs_cis, use_real=True, use_real_unbind_dim=-1):
+    """[EXT] transformer_qwenimage.apply_rotary_emb_qwen, use_real=False (complex) branch.
+    x [B, S, H, D], freqs_cis complex [S, D/2]."""
+    x_rotated = torch.view_as_complex(x.float().reshape(*x.shape[:-1], -1, 2))
+    freqs_cis = freqs_cis.unsqueeze(1)
+    x_out = torch.view_as_real(x_rotated * freqs_cis).flatten(3)
+    return x_out.type_as(x)
+
+
+class _FakeQwenBase(_FakePipelineBase):
+    """[EXT] QwenImageEditPipeline members the reference loop touches (QwenImageEdit/inplace.py:180-420)."""
+
+    @property
+    def attention_kwargs(self):
+        return self._attention_kwargs
+
+
 class _FakeStep1XBase(_FakePipelineBase):
     """[EXT] Step1XEditPipeline members the reference loop touches (Step1XEdit/inplace.py:186-460)."""
 
@@ -497,6 +514,15 @@ def install():
     ts.Step1XEditAttnProcessor = FluxAttnProcessor
     ts.Step1XEditTransformer2DModel = FluxTransformer2DModel
 
+    # Qwen-Image-Edit
+    tq = sys.modules["diffusers.models.transformers.transformer_qwenimage"]
+    tq.apply_rotary_emb_qwen = apply_rotary_emb_qwen
+    tq.QwenImageTransformer2DModel = FluxTransformer2DModel
+    tq.QwenDoubleStreamAttnProcessor2_0 = FluxAttnProcessor
+    sys.modules["diffusers"].QwenImageEditPipeline = type("QwenImageEditPipeline", (_FakeQwenBase,), {})
+    sys.modules["diffusers"].QwenImageEditPlusPipeline = type("QwenImageEditPlusPipeline", (_FakeQwenBase,), {})
+    sys.modules["diffusers.pipelines.qwenimage"].QwenImagePipelineOutput = _BaseOutput
+
     pkg = types.ModuleType("RegionE")
     pkg.__path__ = [REF_ROOT + "/RegionE"]
     pkg._regione_ref = True
@@ -510,6 +536,9 @@ def install():
     ns.step1x_utils = importlib.import_module("RegionE.Step1XEdit.utils")
     ns.step1x.flash_attn = None
     ns.step1x._partially_linear = partially_linear_cpu
+    ns.qwen = importlib.import_module("RegionE.QwenImageEdit.inplace")
+    ns.qwen.flash_attn = None
+    ns.qwen._partially_linear = partially_linear_cpu
     ns.step1x_v1p2 = importlib.import_module("RegionE.Step1XEditV1P2.inplace")
     ns.step1x_v1p2.flash_attn = None
     ns.step1x_v1p2._partially_linear = partially_linear_cpu
