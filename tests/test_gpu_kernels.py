@@ -209,3 +209,69 @@ def test_attention_shapes(Sq, Skv, H):
     qq, kk, vv = (t.to(dev).float().view(-1, H, 128).transpose(0, 1) for t in (q, k, v))
     ref = F.scaled_dot_product_attention(qq[None], kk[None], vv[None])[0].transpose(0, 1).reshape(Sq, D).cpu()
     assert rel_err(out.cpu(), ref) < 1e-2
+
+
+def test_gemm_round_aware_split_k_path():
+    """Shapes whose tile count leaves a partial last round take the split-K remainder + reduce pass
+    (proj_out of a FLUX single block: 408 tiles of 256x256 on 256 CUs).  Reference: fp32 matmul on the GPU."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 8704, 3072, 15360
+    A = bf(torch.randn(M, K, generator=g) * 0.5).cuda()
+    W = bf(torch.randn(N, K, generator=g) * 0.02).cuda()
+    b = bf(torch.randn(N, generator=g)).cuda()
+    gate = bf(torch.randn(N, generator=g)).cuda()
+    resid = bf(torch.randn(M, N, generator=g)).cuda()
+    lin = (A.float() @ W.float().T + b.float())
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, W, b, out)
+    assert rel_err(out.cpu(), lin.cpu()) < 3e-3
+    import os
+    os.environ["RGN_GEMM_SPLIT"] = "0"
+    try:
+        out2 = torch.empty_like(out)
+        ops.gemm(A, W, b, out2)
+    finally:
+        del os.environ["RGN_GEMM_SPLIT"]
+    # split and unsplit schedules agree to fp32 summation order (<= 1 bf16 ulp on a few elements)
+    assert float((out != out2).float().mean()) < 0.02
+    assert float((out.float() - out2.float()).abs().max()) <= 2 ** -7 * float(out2.float().abs().max())
+    x = resid.clone()
+    ops.gemm(A, W, b, x, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=x)
+    ref = resid.float() + (gate.float() * bf(lin).float())
+    assert rel_err(x.cpu(), ref.cpu()) < 4e-3
+
+
+def test_attention_full_size_round_aware_vs_unsplit():
+    """Sq = Skv = 8704, H = 24 (FLUX full step): 816 items = 3 full rounds + 48 remainder items that are cut
+    along KV and merged; must agree with the unsplit schedule and with an fp32 reference on sampled rows."""
+    from regione_amd import ops
+    import os
+    g = torch.Generator().manual_seed(33)
+    S, H = 8704, 24
+    D = H * 128
+    q = bf(torch.randn(S, D, generator=g)).cuda()
+    k = bf(torch.randn(S, D, generator=g)).cuda()
+    v = bf(torch.randn(S, D, generator=g)).cuda()
+    r = torch.arange(S)
+    pos = ((r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)).cuda()
+    vt = torch.zeros(D, S, dtype=torch.bfloat16, device="cuda")
+    vt[:, pos] = v.T
+    out = torch.empty_like(q)
+    ops.attention(q, k, vt, out, S, H)
+    os.environ["RGN_ATTN_VARIANT"] = "8n"
+    try:
+        out2 = torch.empty_like(q)
+        ops.attention(q, k, vt, out2, S, H)
+    finally:
+        del os.environ["RGN_ATTN_VARIANT"]
+    assert rel_err(out.cpu(), out2.cpu()) < 2e-3
+    rows = torch.randperm(S, generator=g)[:256].sort().values.cuda()
+    qq = q[rows].float().view(-1, H, 128).transpose(0, 1)
+    kk, vv = k.float().view(S, H, 128).transpose(0, 1), v.float().view(S, H, 128).transpose(0, 1)
+    ref = F.scaled_dot_product_attention(qq[None], kk[None], vv[None])[0].transpose(0, 1).reshape(len(rows), D)
+    assert rel_err(out[rows].cpu(), ref.cpu()) < 1e-2
+    # in-place form used by the engine (O aliases Q)
+    q2 = q.clone()
+    ops.attention(q2, k, vt, q2, S, H)
+    assert torch.equal(q2, out)
