@@ -314,17 +314,26 @@ def main():
         "loop_mfma_frac": flops_edit / edit_s / 1e12 / PEAK_BF16_TFLOPS,
         "model_build_s": t_build,
     }
+    pmc = {}
+    try:    # PMC passes cannot run inside the timed region: the per-launch HBM-side traffic comes from the committed
+        # rocprofv3 --pmc passes of this same command (profiles/r01_pmc_traffic.json, see its "note")
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    except (OSError, ValueError):
+        pass
     if "gemm_bf16_kernel" in ksum:
         k = ksum["gemm_bf16_kernel"]
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": k["achieved_tflops"],
                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
-                              "traffic": None, "launches": k["launches"], "avg_launch_us": k["avg_us"],
+                              "traffic": pmc.get("gemm_bf16_kernel", {}).get("traffic_bytes_per_launch"),
+                              "traffic_unit": "bytes/launch (L2->fabric reads x2-corrected + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                              "launches": k["launches"], "avg_launch_us": k["avg_us"],
                               "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
     result["gemm_shapes"] = timer.shape_table()
     if "attention_kernel" in ksum:
         k = ksum["attention_kernel"]
         result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_kernel", "achieved": k["achieved_tflops"],
                                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
+                                        "traffic": pmc.get("attention_kernel", {}).get("traffic_bytes_per_launch"),
                                         "launches": k["launches"], "avg_launch_us": k["avg_us"],
                                         "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
 
