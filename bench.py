@@ -196,11 +196,11 @@ def cpu_baseline(cfg, T, N, K_e, plan):
         rope_q = (rope_full[0][sel], rope_full[1][sel])
         h, c = torch.randn(1, K_e, d, generator=g), torch.randn(1, T, d, generator=g)
         t0 = time.perf_counter()
-        c2, h2 = O.double_block(w, "transformer_blocks.0", cfg.heads, st, caches[0], h, c, temb, rope_q, rope_full)
-        times["double_region"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h2, c2, temb, rope_q, rope_full)
+        O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h, c, temb, rope_q, rope_full)
         times["single_region"] = time.perf_counter() - t0
+        # the double block at REGION length is not timed (keeps the sample near 30 s): scaled from the single
+        # block by the FULL-length ratio of the two block types
+        times["double_region"] = times["single_region"] * times["double_full"] / times["single_full"]
     n_full = sum(1 for p in plan if p in "FS")
     n_reg = plan.count("R")
     edit_s = n_full * (cfg.n_double * times["double_full"] + cfg.n_single * times["single_full"]) + \
@@ -215,7 +215,8 @@ def cpu_baseline(cfg, T, N, K_e, plan):
         pass
     return dict(value=N_STEPS / edit_s, unit="steps/s", cores=os.cpu_count(), kind="port",
                 sample=(f"oracle (torch-CPU eager fp32, {os.cpu_count()} threads, {cpu_model}): 1 double + 1 single block at "
-                        f"FULL ({T}+{N} rows) and REGION ({T}+{K_e} query rows) timed once = {sum(times.values()):.1f} s of CPU "
+                        f"FULL ({T}+{N} rows) timed once, 1 single block at REGION ({T}+{K_e} query rows) timed once (double-block REGION "
+                        f"time scaled by the FULL ratio) = {times['double_full'] + times['single_full'] + times['single_region']:.1f} s of CPU "
                         f"work, extrapolated x{cfg.n_double}/{cfg.n_single} layers x plan {n_full}F/{n_reg}R/"
                         f"{plan.count('C')}C -> {edit_s:.0f} s per edit"),
                 block_seconds=times)
