@@ -15,6 +15,9 @@ import torch  # noqa: F401
 
 from .build import LIB_PATH
 
+# developer A/B switch: load another build of the SAME C ABI (never a fallback - it must exist)
+LIB_PATH = os.environ.get("RGN_LIB", LIB_PATH)
+
 _c_void_p, _c_int, _c_float = C.c_void_p, C.c_int, C.c_float
 
 # name -> argtypes (restype is always int unless listed in _RESTYPE)

@@ -160,20 +160,38 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
         nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
 
         // ---- S^T = K Q^T : 2 kv-blocks x 8 k-steps, the two accumulators interleaved --------------
+        // All 16 K fragments are requested from LDS up front (64 VGPRs): left to itself hipcc issues each
+        // ds_read one MFMA ahead and waits lgkmcnt(0) in front of it, exposing the LDS latency 16 times.
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        {
+            bf8_t kf[16];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const int sl = ((ks * 2 + half) ^ k_sw) << 4;
-            const bf8_t kf0 = *(const bf8_t*)(sb + k_row_off + sl);
-            const bf8_t kf1 = *(const bf8_t*)(sb + 32 * 256 + k_row_off + sl);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) {
+                const int sl = ((ks * 2 + half) ^ k_sw) << 4;
+                kf[2 * ks] = *(const bf8_t*)(sb + k_row_off + sl);
+                kf[2 * ks + 1] = *(const bf8_t*)(sb + 32 * 256 + k_row_off + sl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks], qf[ks], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[2 * ks + 1], qf[ks], s1, 0, 0, 0);
+            }
         }
+        // first half of the V^T fragments: requested BEFORE the softmax so their latency hides under its VALU
+        bf8_t vf[16];
+#pragma unroll
+        for (int kb4 = 0; kb4 < 2; ++kb4)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                vf[kb4 * 4 + db] = *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + (((kb4 * 2 + half) ^ v_sw) << 4));
+        __builtin_amdgcn_sched_barrier(0);
         // ---- tail mask ---------------------------------------------------------------------------
         const int kv0 = (t_begin + t) * KV_T;
-        if (kv0 + KV_T > g.Skv) {
+        if (kv0 + KV_T > g.Skv) {                  // last tile only: keep it a real (scalar) branch -
+            asm volatile("; kv tail");             // if-converted it costs ~140 VALU ops on EVERY tile
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -182,9 +200,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
             }
         }
         // ---- online softmax with deferred max -------------------------------------------------------
-        float mx = fmaxf(s0[0], s1[0]);
+        float mx = __builtin_fmaxf(s0[0], s1[0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0[r]), s1[r]);   // v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sl2e;
         if (__any(mx > m_run + DEFER_THR)) {
             const float m_new = fmaxf(m_run, mx);
@@ -196,39 +214,46 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
         }
-        float psum = 0.f;
         bf8_t pf[4];
-        {
-            float p0[16], p1[16];
+        {                                          // P overwrites S in place; packed fp32 math (v_pk_fma/add)
+            const f32x2 sc2 = {sl2e, sl2e}, nm2 = {-m_run, -m_run};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2e, -m_run));
-                p1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2e, -m_run));
-                psum += p0[r] + p1[r];
+            for (int j = 0; j < 8; ++j) {
+                f32x2 a = {s0[2 * j], s0[2 * j + 1]}, b = {s1[2 * j], s1[2 * j + 1]};
+                a = __builtin_elementwise_fma(a, sc2, nm2);
+                b = __builtin_elementwise_fma(b, sc2, nm2);
+                a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+                b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
+                ps2 += a + b;
+                s0[2 * j] = a[0]; s0[2 * j + 1] = a[1];
+                s1[2 * j] = b[0]; s1[2 * j + 1] = b[1];
             }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                uint32_t w0[4], w1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    w0[j] = cvt_pk_bf16(p0[kb * 8 + 2 * j], p0[kb * 8 + 2 * j + 1]);
-                    w1[j] = cvt_pk_bf16(p1[kb * 8 + 2 * j], p1[kb * 8 + 2 * j + 1]);
-                }
-                pf[kb] = *(bf8_t*)w0;
-                pf[2 + kb] = *(bf8_t*)w1;
-            }
+            l_run += ps2[0] + ps2[1];
         }
-        l_run += psum;
-        // ---- O^T += V^T P^T : 4 k-blocks x 4 d-blocks (independent accumulators back to back) -------
 #pragma unroll
-        for (int kb4 = 0; kb4 < 4; ++kb4) {
-            const int sl = ((kb4 * 2 + half) ^ v_sw) << 4;
+        for (int kb = 0; kb < 2; ++kb) {
+            uint32_t w0[4], w1[4];
 #pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const bf8_t vf = *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + sl);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb4], o[db], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                w0[j] = cvt_pk_bf16(s0[kb * 8 + 2 * j], s0[kb * 8 + 2 * j + 1]);
+                w1[j] = cvt_pk_bf16(s1[kb * 8 + 2 * j], s1[kb * 8 + 2 * j + 1]);
             }
+            pf[kb] = *(bf8_t*)w0;
+            pf[2 + kb] = *(bf8_t*)w1;
         }
+        // second half of the V^T fragments, then O^T += V^T P^T : 4 k-blocks x 4 d-blocks
+#pragma unroll
+        for (int kb4 = 2; kb4 < 4; ++kb4)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                vf[kb4 * 4 + db] = *(const bf8_t*)(sb + db * 32 * 128 + v_row_off + (((kb4 * 2 + half) ^ v_sw) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb4 = 0; kb4 < 4; ++kb4)
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kb4 * 4 + db], pf[kb4], o[db], 0, 0, 0);
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmarks of the dominant kernels at the FLUX 1024^2 shapes (GPU box only).
+"""Micro-benchmarks of the dominant kernels at the FLUX 1024^2 shapes (GPU box only), sustained rate.
     python tools/bench_kernels.py [gemm] [attn] [gemv]
 Reports TFLOP/s (algorithmic) per shape, median of N interleaved rounds, uniform random [-1,1) data."""
 import sys, os
@@ -8,15 +8,20 @@ import torch
 from regione_amd import ops
 
 
-def timeit(fn, iters=10, warm=2):
+def timeit(fn, iters=7, warm=2, inner=25):
+    """Median / best over `iters` rounds of `inner` BACK-TO-BACK launches (no host sync inside a round): the
+    engine runs these kernels in a dense stream, and a sync per launch adds ~10 % of clock-ramp/idle time."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(iters):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(); fn(); e.record(); torch.cuda.synchronize()
-        ts.append(s.elapsed_time(e))
+        s.record()
+        for _ in range(inner):
+            fn()
+        e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / inner)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 
