@@ -44,6 +44,10 @@ GAMMA = {
     "qwen": [1.0195, 1.0233, 1.0243, 1.0185, 1.0321, 1.0208, 1.0260, 1.0233, 1.0258,
              1.0292, 1.0316, 1.0306, 1.0289, 1.0347, 1.0329, 1.0402, 1.0378, 1.0384,
              1.0413, 1.0444, 1.0526, 1.0400, 1.0555, 1.0439, 1.0357, 1.0118, 0.7603],
+    # QwenImageEditPlus/inplace.py:47-50
+    "qwen_plus": [1.0186, 1.0241, 1.0236, 1.0205, 1.0298, 1.0221, 1.0248, 1.0246, 1.0269,
+                  1.0275, 1.0323, 1.0311, 1.0298, 1.0353, 1.0343, 1.0397, 1.0387, 1.0393,
+                  1.0404, 1.0458, 1.0507, 1.0418, 1.0518, 1.0426, 1.0311, 1.0068, 0.7628],
     # Step1XEditV1P2/inplace.py:48-50
     "step1x_v1p2": [0.7936, 0.9807, 1.0063, 1.0205, 0.9946, 1.0125, 1.0116, 1.0125, 1.0172,
                     1.0171, 1.0183, 1.0170, 1.0170, 1.0236, 1.0263, 1.0264, 1.0277, 1.0321,

@@ -44,6 +44,32 @@ def test_loop_fixture_bit_exact_on_gpu(golden, name):
     assert torch.equal(out.cpu(), g["final"])
 
 
+@pytest.mark.parametrize("name", ["loop_plan_64", "loop_plan_128"])
+def test_loop_at_baseline_lengths_bit_exact_checksums_on_gpu(golden, name):
+    """The reference loop at the BASELINE token counts (L = 4096 for 1024^2, L = 16384 for 2048^2) on the HIP
+    region kernels: plan, sequence lengths, id count / id checksum and every step's latent checksum are those of
+    the reference run (bit-exact path, so the checksums are compared with ==)."""
+    g = golden(name)
+    h, w = g["h"], g["w"]
+    L = h * w
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=torch.bfloat16)
+    tgt = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    tr = FakeTransformer(torch.cat([tgt, img[0].float()], 0), w, L, device="cuda")
+    pipe = H.FluxKontextPipeline(tr)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=g["threshold"], cache_threshold=g["cache_threshold"], refresh_step=str(g["refresh_step"]))
+    helper.enable()
+    trace = {}
+    pipe(image=img, prompt_embeds=torch.zeros(1, 8, 4), pooled_prompt_embeds=torch.zeros(1, 4), height=h * 16,
+         width=w * 16, latents=lat, return_dict=False, trace=trace)
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    ids = pipe._regione_manager.edited_ids
+    assert ids.numel() == g["n_edited"] and int(ids.sum()) == g["edited_ids_sum"]
+    assert [x.shape[1] for x in trace["latents"]] == g["len"].tolist()
+    assert np.array_equal(np.array([float(x.double().sum()) for x in trace["latents"]]), g["lat_sum"].numpy())
+    assert np.array_equal(np.array([float(x.double().sum()) for x in trace["noise_pred"]]), g["np_sum"].numpy())
+
+
 def _toy_pipe(wts, cfg):
     tr = H.FluxTransformer2DModel(cfg, "cuda").load_state_dict(wts)
     return H.FluxKontextPipeline(tr)

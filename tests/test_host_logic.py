@@ -297,3 +297,13 @@ def test_qwen_plus_dispatch_and_gamma(golden, cpu_ops):
     assert pipe.__class__.__name__ == "RegionEQwenImageEditPlusPipeline"
     assert float(pipe.gamma[0]) == float(qp.gamma[0]) != float(pipe.__class__.__mro__[1].gamma[0])
     assert torch.isfinite(out).all()
+
+
+def test_family_gamma_tables_match_reference_fixture(golden):
+    """Every patch set ships the reference's fitted AVD decay table bit for bit (fp16), tests/golden/avd.npz."""
+    import importlib
+    g = golden("avd")
+    for fam, key in (("FluxKontext", "gamma"), ("Step1XEdit", "gamma_step1x"), ("Step1XEditV1P2", "gamma_step1x_v1p2"),
+                     ("QwenImageEdit", "gamma_qwen"), ("QwenImageEditPlus", "gamma_qwen_plus")):
+        mod = importlib.import_module(f"regione_amd.{fam}.inplace")
+        assert mod.gamma.dtype == torch.float16 and torch.equal(mod.gamma, g[key]), fam

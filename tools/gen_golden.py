@@ -54,7 +54,21 @@ def pack(d):
     return out
 
 
+ONLY = os.environ.get("GOLDEN_ONLY", "")       # substring filter: regenerate just the matching fixtures
+
+
+def wanted(name):
+    return ONLY in name
+
+
 def save(name, d):
+    if "_plan_" in name:
+        # full-length plan fixtures (L = 4096 / 16384): keep the step plan and per-step scalars only
+        ids = d.get("edited_ids")
+        d = {k: v for k, v in d.items() if np.asarray(v if not isinstance(v, torch.Tensor) else v.float().numpy()).size <= 64}
+        if ids is not None:
+            d["n_edited"] = int(ids.numel())
+            d["edited_ids_sum"] = int(ids.long().sum())
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **pack(d))
@@ -217,8 +231,13 @@ def gen_loop(ns):
         ("loop_bf16_32", 32, 32, torch.bfloat16, dict(threshold=0.93, cache_threshold=0.04, refresh_step="16"), (8, 20, 6, 22)),
         ("loop_f32_16", 16, 16, torch.float32, dict(threshold=0.88, cache_threshold=0.02, refresh_step="12,20"), (4, 11, 4, 11)),
         ("loop_bf16_50x83", 50, 83, torch.bfloat16, dict(threshold=0.93, cache_threshold=0.04, refresh_step="16"), (10, 30, 20, 60)),
+        # BASELINE sizes (1024^2 -> 64x64 tokens, 2048^2 -> 128x128): plan / per-step checksums only
+        ("loop_plan_64", 64, 64, torch.bfloat16, dict(threshold=0.88, cache_threshold=0.04, refresh_step="16"), (16, 48, 16, 48)),
+        ("loop_plan_128", 128, 128, torch.bfloat16, dict(threshold=0.88, cache_threshold=0.04, refresh_step="16"), (32, 96, 32, 96)),
     ]
     for name, h, w, dtype, over, box in cfgs:
+        if not wanted(name):
+            continue
         fcfg = synth.FluxConfig()
         latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
         L = h * w
@@ -272,6 +291,19 @@ def gen_avd(ns):
         d[f"L{L}_sigmas"] = sch.sigmas
         d[f"L{L}_ratio"] = np.array(ratios, dtype=np.float32)
     d["gamma"] = ip.gamma
+    # the other families' fitted tables, and their per-step ratios at the BASELINE lengths
+    import importlib
+    fams = {"step1x": ns.step1x, "qwen": ns.qwen, "step1x_v1p2": ns.step1x_v1p2}
+    try:
+        fams["qwen_plus"] = importlib.import_module("RegionE.QwenImageEditPlus.inplace")
+    except Exception as e:                       # noqa: BLE001 - the Plus patch set needs more of diffusers than the stubs give
+        print("   (QwenImageEditPlus not importable here:", type(e).__name__, e, ")")
+    for fam, mod in fams.items():
+        d[f"gamma_{fam}"] = mod.gamma
+        for L in (1024, 4096, 16384):
+            ts = d[f"L{L}_timesteps"]
+            d[f"{fam}_L{L}_ratio"] = np.array([float("nan")] + [float(mod.gamma[i - 1] * (1 + (ts[i] - ts[i - 1]) / 1000))
+                                                                  for i in range(1, 28)], dtype=np.float32)
     save("avd", d)
 
 
@@ -367,7 +399,10 @@ def gen_step1x_loop(ns):
     import diffusers
     ip = ns.step1x
     for name, h, w, dtype, box in (("s1x_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),
-                                   ("s1x_loop_f32_16", 16, 16, torch.float32, (4, 11, 4, 11))):
+                                   ("s1x_loop_f32_16", 16, 16, torch.float32, (4, 11, 4, 11)),
+                                   ("s1x_plan_64", 64, 64, torch.bfloat16, (16, 48, 16, 48))):
+        if not wanted(name):
+            continue
         fcfg = synth.FluxConfig()
         latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
         L = h * w
@@ -457,7 +492,10 @@ def gen_step1x_v1p2_loop(ns):
     text lengths, norm-rescaled CFG, v1p2 gamma), reflection / thinking disabled."""
     import diffusers
     ip = ns.step1x_v1p2
-    for name, h, w, dtype, box in (("s1xv2_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),):
+    for name, h, w, dtype, box in (("s1xv2_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),
+                                   ("s1xv2_plan_128", 128, 128, torch.bfloat16, (32, 96, 32, 96))):
+        if not wanted(name):
+            continue
         fcfg = synth.FluxConfig()
         latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
         L = h * w
@@ -553,7 +591,10 @@ def gen_qwen_loop(ns):
     import diffusers
     ip = ns.qwen
     for name, h, w, dtype, box in (("qwen_loop_bf16_32", 32, 32, torch.bfloat16, (8, 20, 6, 22)),
-                                   ("qwen_loop_f32_16", 16, 16, torch.float32, (4, 11, 4, 11))):
+                                   ("qwen_loop_f32_16", 16, 16, torch.float32, (4, 11, 4, 11)),
+                                   ("qwen_plan_64", 64, 64, torch.bfloat16, (16, 48, 16, 48))):
+        if not wanted(name):
+            continue
         fcfg = synth.FluxConfig()
         latents, image_latents, _, _ = synth.make_edit_inputs(h, w, 8, fcfg, seed=42, dtype=dtype)
         L = h * w

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Host enqueue time vs GPU time of every transformer forward of one RegionE edit (GPU box only).
+    python tools/host_overhead.py [edit_frac] [family]
+A step whose host time is close to its GPU time is launch-bound (the stream runs dry)."""
+import os, sys, time, contextlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench as B
+from regione_amd import RegionEHelper, synth
+from tools.run_configs import weights_stream, make_box
+
+
+def main():
+    frac = float(sys.argv[1]) if len(sys.argv) > 1 else 0.05
+    dev = torch.device("cuda", 0)
+    from regione_amd.harness import flux as HF
+    cfg = synth.FluxConfig()
+    pipe = HF.FluxKontextPipeline(HF.FluxTransformer2DModel(cfg, dev).load_state_dict_stream(weights_stream(cfg, dev, 42)))
+    h = w = 64
+    lat, img, prompt, pooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, 512, cfg, seed=110)]
+    helper = RegionEHelper(pipe)
+    with contextlib.redirect_stdout(sys.stderr):
+        helper.set_params(threshold=0.88, cache_threshold=0.04)
+    helper.enable()
+    B.install_region_injection(pipe, h, w, make_box(h, w, frac), img[0:1], seed=7)
+    rec = []
+    tr = pipe.transformer
+    orig = tr.forward
+
+    def fwd(*a, **k):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        t0 = time.perf_counter()
+        r = orig(*a, **k)
+        host = time.perf_counter() - t0
+        e.record()
+        rec.append((host, s, e, k.get("hidden_states", a[0] if a else None).shape[1]))
+        return r
+    tr.forward = fwd
+
+    def edit():
+        return pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=1024, width=1024, latents=lat,
+                    guidance_scale=2.5, return_dict=False)[0]
+    edit(); rec.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edit()
+    torch.cuda.synchronize()
+    print(f"edit {time.perf_counter()-t0:.3f} s, K_e={pipe._regione_manager.edited_ids.shape[1]}")
+    for i, (host, s, e, n) in enumerate(rec):
+        print(f"forward {i:2d} rows={n:5d} host {host*1e3:7.2f} ms   gpu {s.elapsed_time(e):7.2f} ms")
+
+
+if __name__ == "__main__":
+    main()
