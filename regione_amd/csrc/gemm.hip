@@ -363,38 +363,81 @@ static int check_problem(const void* A, int lda, const void* W, int ldw, const v
 
 static inline int tiles(int M, int N, int b) { return ((M + b - 1) / b) * ((N + b - 1) / b); }
 
+// ------------------------------------------------------------------------------------------------
+// Launch planning.  Both tile configurations are modelled in microseconds with constants measured on
+// MI355X (tools/bench_kernels.py gemm small; uniform random operands, sustained clocks):
+//   256x256 (8 waves, 1 block/CU, 256 slots): a K step of 64 takes ~1.5 us (the chip is then at its power
+//            cap, ~1.2-1.3 PFLOP/s) plus ~10 us of prologue + epilogue per tile.
+//   128x128 (4 waves, 2 blocks/CU): ~0.33 us per K step for one block on a CU; two co-resident blocks
+//            share the CU's MFMA rate, so a launch takes ceil(tiles/256) "rounds" of (nk x 0.36 + 8) us,
+//            and never runs above ~1.05 PFLOP/s chip-wide.
 // Round-aware schedule (same idea as attention_schedule): tiles that fill whole rounds of the chip's
 // workgroup slots run as they are; the remainder is cut along K into nsplit pieces spread over all
-// CUs (fp32 fragment partials in `ws`) and finished by a reduce pass that owns the epilogue.
-template <int BM, int BN, int WM, int WN>
-static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, void* ws, size_t ws_bytes, hipStream_t st) {
-    const int nt = gg.nt;
-    const int K = gg.p[0].K, nk = K / BK;
-    const int full = (nt / slots) * slots, left = nt - full;
-    int best = 1;
-    if (left > 0 && ws != nullptr) {
-        // cost model in microseconds (measured on MI355X: ~4.3 TFLOP/s per CU in the main loop, ~5 us
-        // fixed cost per sub-block, ~10 us of drain per extra launch, partials at ~4 TB/s)
-        const size_t tile_bytes = (size_t)BM * BN * 4;
-        const float t_tile = 2.0f * BM * BN * (float)K / 4.3e12f * 1e6f;
-        const float base = (float)((left + slots - 1) / slots) * t_tile;
-        const float total = (float)((nt + slots - 1) / slots) * t_tile;
-        float best_cost = base;
-        for (int S = 2; S <= 6; ++S) {
-            if (nk / S < 8) break;
-            if ((size_t)left * S * tile_bytes > ws_bytes) break;
-            const float traffic = (float)((size_t)left * S * tile_bytes * 2) / 4.0e12f * 1e6f;
-            const float cost = (float)((left * S + slots - 1) / slots) * (t_tile / (float)S + 5.0f) + traffic + 10.0f;
-            if (cost < best_cost) { best_cost = cost; best = S; }
-        }
-        if (base - best_cost < fmaxf(30.0f, 0.05f * total)) best = 1;      // not worth two extra launches
+// CUs (fp32 fragment partials in `ws`, ~0.07 us of L2/MALL traffic per partial tile) and finished by
+// a reduce pass that owns the epilogue (~10 us for the two extra launches).
+// ------------------------------------------------------------------------------------------------
+struct GemmPlan { int nsplit; float cost_us; };
+
+static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes) {
+    const int slots = 256, nk = K / BK;
+    const size_t tile_bytes = (size_t)256 * 256 * 4;
+    const int full_rounds = nt / slots, left = nt - full_rounds * slots;
+    // FULL mode: 1.5 us per K step + 10 us prologue/epilogue per tile; PARTIAL mode (fp32 fragment dump instead
+    // of the epilogue): 1.45 us + 5 us.  Fits every FLUX shape of tools/bench_kernels.py within ~7 %.
+    const float full_cost = (float)full_rounds * ((float)nk * 1.5f + 10.0f);
+    GemmPlan p{1, full_cost + (left > 0 ? (float)nk * 1.5f + 10.0f : 0.0f)};
+    if (left == 0 || !can_split) return p;
+    const float base = p.cost_us;
+    for (int S = 2; S <= 6; ++S) {
+        if (nk / S < 8) break;
+        if ((size_t)left * S * tile_bytes > ws_bytes) break;
+        const int blocks = left * S, rounds = (blocks + slots - 1) / slots;
+        const float per = (float)((nk + S - 1) / S);
+        const float cost = full_cost + (float)rounds * (per * 1.45f + 5.0f) + 0.07f * (float)blocks + 10.0f;
+        if (cost < p.cost_us) { p.cost_us = cost; p.nsplit = S; }
     }
+    if (base - p.cost_us < fmaxf(30.0f, 0.05f * base)) { p.nsplit = 1; p.cost_us = base; }   // not worth two extra launches
+    return p;
+}
+
+// 128x128 remainder split: few tiles with a long K (text stream, small K_e) spread over the idle CUs
+static int split128(int nt, int K, bool can_split, size_t ws_bytes) {
+    const int slots = 512, nk = K / BK;
+    const int left = nt % slots;
+    if (left == 0 || !can_split) return 1;
+    const size_t tile_bytes = (size_t)128 * 128 * 4;
+    const float t_tile = 2.0f * 128 * 128 * (float)K / 4.3e12f * 1e6f;
+    const float base = (float)((left + slots - 1) / slots) * t_tile;
+    const float total = (float)((nt + slots - 1) / slots) * t_tile;
+    float best_cost = base;
+    int best = 1;
+    for (int S = 2; S <= 6; ++S) {
+        if (nk / S < 8) break;
+        if ((size_t)left * S * tile_bytes > ws_bytes) break;
+        const float traffic = (float)((size_t)left * S * tile_bytes * 2) / 4.0e12f * 1e6f;
+        const float cost = (float)((left * S + slots - 1) / slots) * (t_tile / (float)S + 5.0f) + traffic + 10.0f;
+        if (cost < best_cost) { best_cost = cost; best = S; }
+    }
+    if (base - best_cost < fmaxf(30.0f, 0.05f * total)) best = 1;
+    return best;
+}
+
+static float estimate128(int nt, int K, double flops) {
+    const int nk = K / BK, rounds = (nt + 255) / 256;
+    const float t = (float)rounds * ((float)nk * (nt <= 256 ? 0.33f : 0.36f) + 8.0f);
+    return fmaxf(t, (float)(flops / 1.05e15 * 1e6));
+}
+
+template <int BM, int BN, int WM, int WN>
+static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, void* ws, hipStream_t st) {
+    const int nt = gg.nt;
+    const int full = (nt / slots) * slots, left = nt - full;
     const char* v = getenv("RGN_GEMM_SPLIT");
-    if (v && v[0] == '0') best = 1;
+    if ((v && v[0] == '0') || left == 0) nsplit = 1;
     gg.ws = (float*)ws;
     gg.nsplit = 1;
     int rc;
-    if (best == 1) {
+    if (nsplit == 1) {
         gg.tile_offset = 0; gg.nt_launch = nt;
         return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
     }
@@ -402,19 +445,24 @@ static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, void* ws, size_
         gg.tile_offset = 0; gg.nt_launch = full;
         if ((rc = launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st))) return rc;
     }
-    gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = best;
+    gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = nsplit;
     if ((rc = launch_gemm<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, st))) return rc;
     return launch_gemm<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, st);
 }
 
 static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_t ws_bytes, hipStream_t st) {
-    // tile choice by estimated throughput = asymptotic rate x wave-quantisation efficiency:
-    // 256x256 (1 block/CU, 256 slots, ~1150 TF) vs 128x128 (2 blocks/CU, 512 slots, ~1000 TF)
     int big = 0, small_ = 0;
-    for (int i = 0; i < nprob; ++i) { big += tiles(gg.p[i].M, gg.p[i].N, 256); small_ += tiles(gg.p[i].M, gg.p[i].N, 128); }
-    const float eff_big = (float)big / (float)(((big + 255) / 256) * 256);
-    const float eff_small = (float)small_ / (float)(((small_ + 511) / 512) * 512);
-    bool use_big = ws ? (big >= 200) : (1150.f * eff_big > 1000.f * eff_small);   // with the split remainder, quantisation no longer decides
+    double flops = 0.0;
+    for (int i = 0; i < nprob; ++i) {
+        big += tiles(gg.p[i].M, gg.p[i].N, 256);
+        small_ += tiles(gg.p[i].M, gg.p[i].N, 128);
+        flops += 2.0 * gg.p[i].M * (double)gg.p[i].N * gg.p[i].K;
+    }
+    const int K = gg.p[0].K;
+    const GemmPlan p256 = plan256(big, K, ws != nullptr, ws_bytes);
+    const float e128 = estimate128(small_, K, flops);
+    // the model is coarse: leave the habitual choice (256x256 from ~200 tiles up) only for a clear predicted win
+    bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < 0.92f * e128);
     const char* v = getenv("RGN_GEMM_VARIANT");
     if (v && v[0] == '1') use_big = false;
     if (v && v[0] == '2') use_big = true;
@@ -422,8 +470,8 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
     if (gg.nt == 0) return 0;
-    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, ws, ws_bytes, st)
-                   : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, ws, ws_bytes, st);
+    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, p256.nsplit, ws, st)
+                   : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, split128(gg.nt, K, ws != nullptr, ws_bytes), ws, st);
 }
 
 static void fill(GemmArgs& g, const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M,

@@ -48,6 +48,31 @@ def bench_gemm():
         del A, W, out
 
 
+def bench_small():
+    """Region-step shapes (M = T + K_e): single GEMMs and the text+image pairs of the double blocks."""
+    singles = [("R proj_out", 1536, 3072, 15360), ("R kvq+mlp", 1536, 21504, 3072), ("R5% proj_out", 708, 3072, 15360),
+               ("R5% kvq+mlp", 708, 21504, 3072), ("R50% proj_out", 2537, 3072, 15360)]
+    pairs = [("R qkv", 1024, 512, 9216, 3072), ("R out", 1024, 512, 3072, 3072), ("R ff1", 1024, 512, 12288, 3072),
+             ("R ff2", 1024, 512, 3072, 12288), ("R5% ff2", 196, 512, 3072, 12288), ("R5% ff1", 196, 512, 12288, 3072),
+             ("Qwen R ff2 T384", 1024, 384, 3072, 12288)]
+    for name, M, N, K in singles:
+        A, W, b = rnd(M, K), rnd(N, K) * 0.05, rnd(N)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        for variant in VARIANTS:
+            os.environ["RGN_GEMM_VARIANT"] = variant
+            med, best = timeit(lambda: ops.gemm(A, W, b, out))
+            fl = 2.0 * M * N * K
+            print(f"gemm[{variant:>4}] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  (ideal@1150 {fl/1150e6:6.1f} us)")
+    for name, M0, M1, N, K in pairs:
+        A0, A1, W0, W1, b = rnd(M0, K), rnd(M1, K), rnd(N, K) * 0.05, rnd(N, K) * 0.05, rnd(N)
+        o0, o1 = torch.empty(M0, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M1, N, dtype=torch.bfloat16, device="cuda")
+        for variant in VARIANTS:
+            os.environ["RGN_GEMM_VARIANT"] = variant
+            med, best = timeit(lambda: ops.gemm_pair(A0, W0, b, o0, A1, W1, b, o1))
+            fl = 2.0 * (M0 + M1) * N * K
+            print(f"pair[{variant:>4}] {name:<18} M={M0}+{M1:<4} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  (ideal@1150 {fl/1150e6:6.1f} us)")
+
+
 def bench_attn():
     for name, Sq, Skv, H in [("full", 8704, 8704, 24), ("region 25%", 1536, 8704, 24), ("region 5%", 717, 8704, 24)]:
         D = H * 128
@@ -72,5 +97,6 @@ AVARIANTS = os.environ.get("ATTN_VARIANTS", "auto").split(",")   # e.g. 8,8n,4,4
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "gemv"]
     if "gemm" in which: bench_gemm()
+    if "small" in which: bench_small()
     if "attn" in which: bench_attn()
     if "gemv" in which: bench_gemv()
