@@ -69,7 +69,24 @@ class KernelTimer:
     def wrap(self, ops_mod):
         import regione_amd.ops as ops
         self._orig_gemm, self._orig_attn, self._orig_pair = ops.gemm, ops.attention, ops.gemm_pair
+        self._orig_qkv, self._orig_qkv_pair = ops.gemm_qkv, ops.gemm_qkv_pair
         timer = self
+
+        def timed_gemm(fn, m0, m1, N, K, *a, **kw):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = fn(*a, **kw)
+            e.record()
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (m0 + m1) * N * K))
+            timer.shapes.setdefault((m0, m1, N, K), []).append((s, e))
+            return r
+
+        def gemm_qkv(A, W, bias, out, epi, **kw):          # fused Q/K/V epilogue: same FLOPs, epilogue work included
+            return timed_gemm(timer._orig_qkv, A.shape[0], 0, W.shape[0], A.shape[1], A, W, bias, out, epi, **kw)
+
+        def gemm_qkv_pair(A0, W0, b0, o0, e0, A1, W1, b1, o1, e1):
+            return timed_gemm(timer._orig_qkv_pair, A0.shape[0], A1.shape[0], W0.shape[0], W0.shape[1],
+                              A0, W0, b0, o0, e0, A1, W1, b1, o1, e1)
 
         def gemm_pair(A0, W0, b0, o0, A1, W1, b1, o1, **kw):
             N, K = W0.shape
@@ -101,10 +118,12 @@ class KernelTimer:
             return r
 
         ops.gemm, ops.attention, ops.gemm_pair = gemm, attention, gemm_pair
+        ops.gemm_qkv, ops.gemm_qkv_pair = gemm_qkv, gemm_qkv_pair
 
     def unwrap(self):
         import regione_amd.ops as ops
         ops.gemm, ops.attention, ops.gemm_pair = self._orig_gemm, self._orig_attn, self._orig_pair
+        ops.gemm_qkv, ops.gemm_qkv_pair = self._orig_qkv, self._orig_qkv_pair
 
     def summary(self):
         out = {}

@@ -132,6 +132,39 @@ int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bia
                        int N, int K, int epilogue, int gelu_from_col, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* Fused QKV projection (reference: the Linear projections + `attn.norm_q/k` + `apply_rotary_emb` + K/V cache
+ * placement of RegoionEFluxAttnProcessor2_0.__call__, FluxKontext/inplace.py:735-794; the K/V partial update
+ * `_partially_linear`, fused_kernels.py:81-101).  Same GEMM as rgn_gemm_bf16, but the epilogue of each 256-column
+ * block of C does what rgn_qk_norm_rope_store does as a separate pass:
+ *   columns [k_col, k_col + heads*128): per-head RMSNorm + RoPE (k tables, row kv_rows[r]) -> k_slab row kv_rows[r]
+ *   columns [v_col, ...):               transposed into vt_slab (kv index permuted as rgn_attention expects)
+ *   columns [q_col, ...):               per-head RMSNorm + RoPE (q tables, row r) -> C in place
+ *   columns >= gelu_from_col:           GELU-tanh -> C           (the fused MLP half of a single-stream block)
+ * K and V columns are NOT written to C.  r = row_base + local row (row_base: where this problem's rows sit in
+ * the joint [text | image] sequence that the tables / kv_rows are indexed by).  Results are bit-identical to
+ * rgn_gemm_bf16 followed by rgn_qk_norm_rope_store. */
+typedef struct rgn_qkv_epilogue {
+    const void* wq;            /* [128] bf16 RMSNorm weights of this stream (norm_q / norm_added_q) */
+    const void* wk;
+    const float* cos_q;        /* [rows][128] fp32 */
+    const float* sin_q;
+    const float* cos_k;
+    const float* sin_k;
+    const int64_t* kv_rows;    /* joint row -> K/V cache row, NULL = identity */
+    void* k_slab;              /* [kv rows][heads*128] bf16 */
+    void* vt_slab;             /* [heads*128][skv_pad] bf16 */
+    int row_base, skv_pad, k_col, v_col, q_col, heads;
+    float eps;
+} rgn_qkv_epilogue;
+#define RGN_EPI_QKV 3
+int rgn_gemm_bf16_qkv(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
+                      int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int rgn_gemm_bf16_qkv_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
+                           const rgn_qkv_epilogue* e0, const void* A1, int lda1, const void* W1, const void* bias1,
+                           void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K, void* workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Skinny GEMV for the AdaLN modulation / timestep embedders:
  *   y[b,n] = bf16( sum_k W[n,k] * act(x[b,k]) + bias[n] ),  act = silu (rounded to bf16) if silu_input.
  * B <= 4, K % 8 == 0.  HBM-bound on W. */

@@ -20,6 +20,18 @@ LIB_PATH = os.environ.get("RGN_LIB", LIB_PATH)
 
 _c_void_p, _c_int, _c_float = C.c_void_p, C.c_int, C.c_float
 
+
+
+class QkvEpilogue(C.Structure):
+    """struct rgn_qkv_epilogue (include/regione_hip.h)."""
+    _fields_ = [("wq", _c_void_p), ("wk", _c_void_p), ("cos_q", _c_void_p), ("sin_q", _c_void_p), ("cos_k", _c_void_p),
+                ("sin_k", _c_void_p), ("kv_rows", _c_void_p), ("k_slab", _c_void_p), ("vt_slab", _c_void_p),
+                ("row_base", _c_int), ("skv_pad", _c_int), ("k_col", _c_int), ("v_col", _c_int), ("q_col", _c_int),
+                ("heads", _c_int), ("eps", _c_float)]
+
+
+_qkv_p = C.POINTER(QkvEpilogue)
+
 # name -> argtypes (restype is always int unless listed in _RESTYPE)
 SIGNATURES = {
     "rgn_version": [],
@@ -38,6 +50,11 @@ SIGNATURES = {
     "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                       _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemm_workspace_bytes": [],
+    "rgn_gemm_bf16_qkv": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                          _qkv_p, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_gemm_bf16_qkv_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _qkv_p,
+                               _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _qkv_p,
+                               _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemm_bf16_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                            _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                            _c_int, _c_int, _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],

@@ -24,15 +24,18 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
-// torch-compatible round-to-nearest-even fp32 -> bf16 (NaN -> 0x7fc0).
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even like torch: the gfx950 hardware convert (v_cvt_pk_bf16_f32, two values per
+// instruction).  Identical to the add-0x7fff bit trick for every finite value and infinity; a NaN stays a quiet
+// NaN (torch canonicalises it to 0x7fc0 - no finite computation on this path produces one).
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float hw_f32x2;
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+    hw_bf16x2 r = __builtin_convertvector(hw_f32x2{lo, hi}, hw_bf16x2);
+    return *(uint32_t*)&r;
 }
+__device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)f2bf_pk(f, 0.f); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }   // round through bf16
+__device__ __forceinline__ float rbf(float f) { return __uint_as_float(f2bf_pk(f, 0.f) << 16); }   // round through bf16
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

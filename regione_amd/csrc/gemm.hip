@@ -27,7 +27,24 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+// RGN_EPI_QKV: what the separate qk_norm_rope / v_transpose_store kernels do, applied to the staged C tile
+struct QkvEpi {
+    const uint16_t* wq;          // RMSNorm weights [128] of this problem's stream
+    const uint16_t* wk;
+    const float* cos_q;          // [rows][128] fp32 tables: q rows are indexed by the sequence row, k rows by kv row
+    const float* sin_q;
+    const float* cos_k;
+    const float* sin_k;
+    const int64_t* kv_rows;      // sequence row -> K/V cache row (nullptr = identity)
+    uint16_t* k_slab;            // [kv rows][heads * 128]
+    uint16_t* vt_slab;           // [heads * 128][skv_pad], kv index permuted inside 16-groups
+    int row_base;                // sequence row of this problem's row 0
+    int skv_pad, k_col, v_col, q_col, hd;     // hd = heads * 128
+    float eps;
+};
+
 struct GemmArgs {
+    QkvEpi qkv;
     const uint16_t* A;
     const uint16_t* W;
     const uint16_t* bias;
@@ -57,6 +74,45 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     return *(uint32_t*)&r;
 }
 
+__device__ __forceinline__ size_t kvpos(size_t r) { return (r & ~(size_t)12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// Per-head RMSNorm + RoPE of 8 consecutive columns of one row (16 lanes = one 128-wide head).  Same
+// arithmetic and the SAME summation tree as qk_norm_rope_kernel (norm.hip), so both paths agree bit for bit.
+struct RopeTab { float4 c0, c1, s0, s1; };
+
+__device__ __forceinline__ RopeTab load_rope(const float* __restrict__ cos8, const float* __restrict__ sin8) {
+    RopeTab t;
+    t.c0 = *(const float4*)cos8; t.c1 = *(const float4*)(cos8 + 4);
+    t.s0 = *(const float4*)sin8; t.s1 = *(const float4*)(sin8 + 4);
+    return t;
+}
+
+__device__ __forceinline__ void qk_norm_rope_vec(uint16_t (&v)[8], const uint16_t (&wv)[8], float eps, const RopeTab& t) {
+#pragma clang fp contract(off)
+    float x[8], p[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = bf2f(v[e]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] = x[2 * j] * x[2 * j] + x[2 * j + 1] * x[2 * j + 1];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] += __shfl_xor(p[j], o, 64);
+    const float ss = (p[0] + p[2]) + (p[1] + p[3]);
+    const float r = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
+    const float cc[8] = {t.c0.x, t.c0.y, t.c0.z, t.c0.w, t.c1.x, t.c1.y, t.c1.z, t.c1.w};
+    const float sn[8] = {t.s0.x, t.s0.y, t.s0.z, t.s0.w, t.s1.x, t.s1.y, t.s1.z, t.s1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = rbf(rbf(x[2 * j] * r) * bf2f(wv[2 * j]));
+        const float b = rbf(rbf(x[2 * j + 1] * r) * bf2f(wv[2 * j + 1]));
+        const float o0 = a * cc[2 * j] + (-b) * sn[2 * j];
+        const float o1 = b * cc[2 * j + 1] + a * sn[2 * j + 1];
+        v[2 * j] = f2bf(o0);
+        v[2 * j + 1] = f2bf(o1);
+    }
+}
+
 struct GemmGroup {
     GemmArgs p[2];      // up to two problems per launch (e.g. text + image stream of a double block)
     int nt0;            // tiles of problem 0; tiles >= nt0 belong to problem 1
@@ -81,7 +137,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB DMA pieces per wave per stage
     constexpr int CT_LD = BN + 8;                              // padded bf16 row of the C staging tile
-    constexpr int CROWS = BM / WM;                             // C rows staged per epilogue chunk
+    // C rows staged per epilogue chunk: one wave row at a time (the staging tile then fits inside the K-loop
+    // stages), except for the fused Q/K/V epilogue, which stages the whole tile at once so that no wave keeps its
+    // 128 accumulator registers alive while the others run the (register-hungry) norm / RoPE passes
+    constexpr int NCH = (EPI == RGN_EPI_QKV) ? 1 : WM;
+    constexpr int CROWS = BM / NCH;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -211,6 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
 
     // ---- epilogue: per row-chunk (one wave row): acc + bias -> bf16 -> LDS -> 16-byte stores ------
     uint16_t* ct = (uint16_t*)smem;                 // CROWS x CT_LD bf16 (stages are free now)
+    int* krow = (int*)(smem + CROWS * CT_LD * 2);   // CROWS cache-row indices (RGN_EPI_QKV)
     constexpr int VPR = BN / 8;                     // 8-column vectors per tile row
     constexpr int RPP = NT / VPR;                   // rows per store pass
     const int vc = tid % VPR;
@@ -222,8 +283,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
         for (int e = 0; e < 8; ++e) gv[e] = (ncol + e < g.N) ? g.gate[ncol + e] : 0;
     }
 #pragma unroll
-    for (int ch = 0; ch < WM; ++ch) {
-        if (wm == ch) {
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (NCH == 1 || wm == ch) {
+            const int crow0 = (NCH == 1) ? wm * (BM / WM) : 0;
             // operands are fed swapped (W fragment as the MFMA row operand), so a lane's 4 accumulator
             // registers are 4 CONSECUTIVE COLUMNS of one output row: one 8-byte LDS write per fragment
             const int mrow = lane & 15, ncol4 = (lane >> 4) * 4;
@@ -243,11 +305,95 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
                 for (int i = 0; i < TM; ++i) {
                     const uint2 w = make_uint2(cvt_pk_bf16(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
                                                cvt_pk_bf16(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
-                    *(uint2*)(ct + (i * 16 + mrow) * CT_LD + nl) = w;
+                    *(uint2*)(ct + (crow0 + i * 16 + mrow) * CT_LD + nl) = w;
                 }
             }
         }
+        if (EPI == RGN_EPI_QKV && tid < CROWS) {
+            // cache rows of this chunk's sequence rows: one coalesced load per chunk instead of a dependent
+            // global load in front of every K / V^T store
+            const int ml = m0 + ch * CROWS + tid;
+            const int sr = g.qkv.row_base + ml;
+            krow[tid] = (ml < g.M) ? (g.qkv.kv_rows ? (int)g.qkv.kv_rows[sr] : sr) : -1;
+        }
         __syncthreads();
+        if (EPI == RGN_EPI_QKV && n0 >= g.qkv.v_col && n0 < g.qkv.v_col + g.qkv.hd) {
+            // ---- V tile: transposed into the V^T slab (kv index bits 2<->3 swapped inside 16-groups) ----
+            // item = (column d, 16-row group a, half p): rows 16a + {4p..4p+3, 8+4p..8+4p+3} are 8 CONSECUTIVE
+            // slab positions 16a + 8p .. +7  ->  one 16-byte store when the kv rows are the identity
+            const QkvEpi& q = g.qkv;
+            const int rbase = q.row_base + m0 + ch * CROWS;                 // sequence row of chunk row 0
+            const bool ident = (q.kv_rows == nullptr) && ((rbase & 15) == 0);
+            constexpr int ITEMS = BN * (CROWS / 8) / NT;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int item = tid + j * NT;
+                const int col = item % BN, grp = item / BN;
+                const int a = grp >> 1, ph = grp & 1;
+                const int hd_col = n0 - q.v_col + col;                      // h * 128 + d
+                if (hd_col >= q.hd) continue;
+                uint16_t t[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = ct[(16 * a + 4 * ph + (e & 3) + 8 * (e >> 2)) * CT_LD + col];
+                uint16_t* drow = q.vt_slab + (size_t)hd_col * q.skv_pad;
+                const int mlast = m0 + ch * CROWS + 16 * a + 4 * ph + 11;   // largest local row of the item
+                if (ident && mlast < g.M) {
+                    *(uint4*)(drow + rbase + 16 * a + 8 * ph) = *(const uint4*)t;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kr = krow[16 * a + 4 * ph + (e & 3) + 8 * (e >> 2)];
+                        if (kr >= 0) drow[kvpos((size_t)kr)] = t[e];
+                    }
+                }
+            }
+            if (ch + 1 < NCH) __syncthreads();
+            continue;
+        }
+        const bool qk_tile = (EPI == RGN_EPI_QKV) && n0 < g.qkv.q_col + g.qkv.hd &&
+                             (n0 >= g.qkv.q_col || (n0 >= g.qkv.k_col && n0 < g.qkv.k_col + g.qkv.hd));
+        if (EPI == RGN_EPI_QKV && qk_tile) {
+            // ---- Q / K tile: per-head RMSNorm + RoPE; Q goes back to C in place, K to its cache row.  The
+            // cos / sin rows of the next two passes are in flight while this pass computes. ----
+            const QkvEpi& q = g.qkv;
+            const bool k_tile = !(n0 >= q.q_col);
+            const int hc = ncol - (k_tile ? q.k_col : q.q_col);            // h * 128 + c, c = 8 * (lane in head)
+            const float* cos_t = (k_tile ? q.cos_k : q.cos_q) + (hc & 127);
+            const float* sin_t = (k_tile ? q.sin_k : q.sin_q) + (hc & 127);
+            uint16_t wv[8];
+            *(uint4*)wv = *(const uint4*)((k_tile ? q.wk : q.wq) + (hc & 127));
+            constexpr int NIT = CROWS / RPP, DEPTH = 2;
+            auto tab_row = [&](int it) -> size_t {                          // clamped: rows >= M load row 0, never stored
+                const int row = tid / VPR + it * RPP;
+                const int kr = krow[row];
+                return kr < 0 ? 0 : (k_tile ? (size_t)kr : (size_t)(q.row_base + m0 + ch * CROWS + row));
+            };
+            RopeTab tab[DEPTH];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const size_t tr = tab_row(d);
+                tab[d] = load_rope(cos_t + tr * 128, sin_t + tr * 128);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int row = tid / VPR + it * RPP;
+                const int m = m0 + ch * CROWS + row;
+                uint16_t v[8];
+                *(uint4*)v = *(const uint4*)(ct + row * CT_LD + vc * 8);
+                const RopeTab t = tab[it % DEPTH];
+                if (it + DEPTH < NIT) {
+                    const size_t tr = tab_row(it + DEPTH);
+                    tab[it % DEPTH] = load_rope(cos_t + tr * 128, sin_t + tr * 128);
+                }
+                qk_norm_rope_vec(v, wv, q.eps, t);
+                if (m < g.M) {
+                    uint16_t* dst = k_tile ? q.k_slab + (size_t)krow[row] * q.hd + hc : g.C + (size_t)m * g.ldc + ncol;
+                    *(uint4*)dst = *(const uint4*)v;
+                }
+            }
+            if (ch + 1 < NCH) __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < CROWS / RPP; ++it) {
             const int row = tid / VPR + it * RPP;
@@ -257,7 +403,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
             uint16_t v[8];
             *(uint4*)v = *(const uint4*)(ct + row * CT_LD + vc * 8);
             uint16_t* dst = g.C + orow * g.ldc + ncol;
-            if (EPI == RGN_EPI_GELU) {
+            if (false) {
+            } else if (EPI == RGN_EPI_QKV) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));
+            } else if (EPI == RGN_EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));
@@ -278,7 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
                 for (int e = 0; e < 8; ++e)
                     if (ncol + e < g.N) dst[e] = v[e];
         }
-        if (ch + 1 < WM) __syncthreads();
+        if (ch + 1 < NCH) __syncthreads();
     }
 }
 
@@ -327,12 +478,15 @@ using namespace rgn;
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
     constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    constexpr int QKV_TILE = BM * (BN + 8) * 2 + BM * 4;            // whole staged C tile + cache-row table
+    constexpr int LDS_QKV = QKV_TILE > LDS ? QKV_TILE : LDS;
     constexpr int NT = 64 * WM * WN;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_QKV, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_QKV);
         attr = true;
     }
     const int nb = (MODE == MODE_PARTIAL) ? gg.nt_launch * gg.nsplit : gg.nt_launch;
@@ -345,6 +499,7 @@ static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
         case RGN_EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
         case RGN_EPI_GELU: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
         case RGN_EPI_GATE_RESID: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_QKV: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_QKV, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS_QKV, st, gg); break;
         default: return fail(RGN_E_BADARG, "gemm: unknown epilogue");
     }
     return check_launch("gemm_bf16_kernel");
@@ -478,7 +633,27 @@ static void fill(GemmArgs& g, const void* A, int lda, const void* W, int ldw, co
                  int N, int K, int gelu_from_col, const void* gate, const void* resid, const int64_t* out_rows) {
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.bias = (const uint16_t*)bias; g.C = (uint16_t*)C;
     g.gate = (const uint16_t*)gate; g.resid = (const uint16_t*)resid; g.out_rows = out_rows;
+    g.qkv = QkvEpi{};
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.gelu_from_col = gelu_from_col;
+}
+
+static int fill_qkv(GemmArgs& g, const rgn_qkv_epilogue* e, int N) {
+    if (!e || !e->wq || !e->wk || !e->cos_q || !e->sin_q || !e->cos_k || !e->sin_k || !e->k_slab || !e->vt_slab)
+        return fail(RGN_E_BADARG, "gemm_qkv: null pointer in rgn_qkv_epilogue");
+    const int hd = e->heads * 128;
+    if (e->heads <= 0 || (e->k_col % 256) || (e->v_col % 256) || (e->q_col % 256) || (hd % 256) || (e->skv_pad % 64) ||
+        e->k_col + hd > N || e->v_col + hd > N || e->q_col + hd > N || e->row_base < 0)
+        return fail(RGN_E_UNSUPPORTED, "gemm_qkv: k/v/q column blocks must be 256-aligned blocks of heads*128 columns inside N");
+    if ((((uintptr_t)e->wq | (uintptr_t)e->wk | (uintptr_t)e->cos_q | (uintptr_t)e->sin_q | (uintptr_t)e->cos_k |
+          (uintptr_t)e->sin_k | (uintptr_t)e->k_slab | (uintptr_t)e->vt_slab) & 15) != 0)
+        return fail(RGN_E_UNSUPPORTED, "gemm_qkv: pointers must be 16-byte aligned");
+    QkvEpi& q = g.qkv;
+    q.wq = (const uint16_t*)e->wq; q.wk = (const uint16_t*)e->wk;
+    q.cos_q = e->cos_q; q.sin_q = e->sin_q; q.cos_k = e->cos_k; q.sin_k = e->sin_k;
+    q.kv_rows = e->kv_rows; q.k_slab = (uint16_t*)e->k_slab; q.vt_slab = (uint16_t*)e->vt_slab;
+    q.row_base = e->row_base; q.skv_pad = e->skv_pad; q.k_col = e->k_col; q.v_col = e->v_col; q.q_col = e->q_col;
+    q.hd = hd; q.eps = e->eps;
+    return 0;
 }
 
 extern "C" {
@@ -510,6 +685,37 @@ int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bia
     fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, gelu_from_col, gate0, resid0, nullptr);
     fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, gelu_from_col, gate1, resid1, nullptr);
     return gemm_dispatch(gg, 2, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int rgn_gemm_bf16_qkv(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
+                      int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace, size_t workspace_bytes,
+                      void* stream) {
+    if (M == 0) return 0;
+    int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, RGN_EPI_QKV, nullptr, nullptr);
+    if (rc) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, nullptr, nullptr, nullptr);
+    if ((rc = fill_qkv(gg.p[0], e, N))) return rc;
+    gg.p[1] = gg.p[0];
+    return gemm_dispatch(gg, 1, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int rgn_gemm_bf16_qkv_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
+                           const rgn_qkv_epilogue* e0, const void* A1, int lda1, const void* W1, const void* bias1,
+                           void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+    if (M0 == 0 && M1 == 0) return 0;
+    if (M0 == 0) return rgn_gemm_bf16_qkv(A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, N, e1, workspace, workspace_bytes, stream);
+    if (M1 == 0) return rgn_gemm_bf16_qkv(A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, N, e0, workspace, workspace_bytes, stream);
+    int rc = check_problem(A0, lda0, W0, K, C0, ldc0, M0, N, K, RGN_EPI_QKV, nullptr, nullptr);
+    if (rc) return rc;
+    if ((rc = check_problem(A1, lda1, W1, K, C1, ldc1, M1, N, K, RGN_EPI_QKV, nullptr, nullptr))) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, N, nullptr, nullptr, nullptr);
+    fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, N, nullptr, nullptr, nullptr);
+    if ((rc = fill_qkv(gg.p[0], e0, N))) return rc;
+    if ((rc = fill_qkv(gg.p[1], e1, N))) return rc;
+    return gemm_dispatch(gg, 2, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 size_t rgn_gemm_workspace_bytes(void) { return (size_t)256 << 20; }

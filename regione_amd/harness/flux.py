@@ -27,6 +27,7 @@ Engine layout (one image, B = 1):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -189,6 +190,11 @@ class FwdCtx:
 # ---------------------------------------------------------------------------------------------
 # [EXT] module tree
 # ---------------------------------------------------------------------------------------------
+# RGN_FUSE_QKV=0 keeps RMSNorm / RoPE / cache placement as the separate rgn_qk_norm_rope_store pass (A/B switch;
+# both paths produce bit-identical results, tests/test_gpu_kernels.py)
+FUSE_QKV = os.environ.get("RGN_FUSE_QKV", "1") != "0"
+
+
 class Attention:
     """Weight container + processor slot (diffusers.models.attention_processor.Attention)."""
 
@@ -223,11 +229,21 @@ class FluxAttnProcessor:
         wide = ws.wide[:R]
         k_slab, vt_slab, kv_rows, skv, rope_k = self.kv_target(attn, ctx)
         rope_k = rope_k if rope_k is not None else image_rotary_emb
+        fuse = FUSE_QKV and H % 2 == 0             # the fused epilogue works on 256-column (two-head) blocks
+        if fuse:
+            epi = dict(rope_q=image_rotary_emb, rope_k=rope_k, k_slab=k_slab, vt_slab=vt_slab, H=H, k_col=0, v_col=d,
+                       q_col=2 * d, kv_rows=kv_rows)
         if not self.single:
-            ops.gemm_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
-                          ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d])
-            ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
-                                   k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
+            if fuse:       # projections + RMSNorm + RoPE + K / V^T cache placement of both streams: ONE launch
+                ops.gemm_qkv_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
+                                  ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, row_base=T, **epi),
+                                  ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d],
+                                  ops.qkv_epilogue(wq=attn.norm_added_q, wk=attn.norm_added_k, row_base=0, **epi))
+            else:
+                ops.gemm_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
+                              ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d])
+                ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
+                                       k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
             q = wide[:, 2 * d:3 * d]
             ops.attention(q, k_slab, vt_slab, q, skv, H)
             g_img, g_txt = block.gates_msa(ctx)
@@ -235,9 +251,13 @@ class FluxAttnProcessor:
                           epilogue=ops.EPI_GATE_RESID, gate0=g_img, resid0=ws.x[T:R], gate1=g_txt, resid1=ws.x[:T])
             return ws.x[T:R], ws.x[:T]
         # single stream: one GEMM produces [k | v | q | gelu(mlp)] from the same normed activations
-        ops.gemm(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * d)
-        ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
-                               vt_slab, kv_rows)
+        if fuse:
+            ops.gemm_qkv(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, **epi),
+                         gelu_from_col=3 * d)
+        else:
+            ops.gemm(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * d)
+            ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
+                                   vt_slab, kv_rows)
         q = wide[:, 2 * d:3 * d]
         ops.attention(q, k_slab, vt_slab, q, skv, H)
         return wide[:, 2 * d:]                                       # cat([attn_output, mlp_hidden], dim=2)

@@ -194,6 +194,48 @@ def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, g
     _lib.check(rc, "rgn_gemm_bf16_pair")
 
 
+def qkv_epilogue(*, wq, wk, rope_q, rope_k, k_slab, vt_slab, H: int, k_col: int, v_col: int, q_col: int,
+                 kv_rows: Optional[torch.Tensor] = None, row_base: int = 0, eps: float = 1e-6):
+    """Descriptor of the fused Q/K/V epilogue (struct rgn_qkv_epilogue); keeps its tensors alive."""
+    skv_pad = k_slab.shape[0]
+    assert vt_slab.shape == (H * 128, skv_pad) and k_slab.shape[1] == H * 128 and k_slab.is_contiguous() and vt_slab.is_contiguous()
+    for t in (rope_q[0], rope_q[1], rope_k[0], rope_k[1]):
+        assert t.dtype == torch.float32 and t.shape[1] == 128 and t.is_contiguous()
+    e = _lib.QkvEpilogue(_p(wq), _p(wk), _p(rope_q[0]), _p(rope_q[1]), _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows),
+                         _p(k_slab), _p(vt_slab), row_base, skv_pad, k_col, v_col, q_col, H, eps)
+    e._keep = (wq, wk, rope_q, rope_k, kv_rows, k_slab, vt_slab)
+    return e
+
+
+def gemm_qkv(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, epi, *,
+             gelu_from_col: Optional[int] = None) -> torch.Tensor:
+    """QKV (+ fused MLP half) projection whose epilogue normalises / rotates Q and K, places K and V^T in the
+    cache slabs and leaves Q (and GELU(mlp)) in `out`: rgn_gemm_bf16 + rgn_qk_norm_rope_store in one launch."""
+    assert A.dtype == W.dtype == out.dtype == torch.bfloat16
+    M, K = A.shape
+    N = W.shape[0]
+    assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and W.shape[1] == K and out.shape[1] == N
+    ws = gemm_workspace(A.device)
+    rc = _lib.lib().rgn_gemm_bf16_qkv(_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                      N if gelu_from_col is None else gelu_from_col, epi, _p(ws), ws.numel() * 4, _stream())
+    _lib.check(rc, "rgn_gemm_bf16_qkv")
+    return out
+
+
+def gemm_qkv_pair(A0, W0, b0, out0, epi0, A1, W1, b1, out1, epi1):
+    """Both streams of a double block (image + text QKV projections) in one launch, fused Q/K/V epilogue."""
+    N, K = W0.shape
+    assert W1.shape == (N, K) and W0.is_contiguous() and W1.is_contiguous()
+    assert A0.shape[1] == K and A1.shape[1] == K and out0.shape[1] == N and out1.shape[1] == N
+    for t in (A0, A1, out0, out1):
+        assert t.stride(1) == 1 and t.dtype == torch.bfloat16
+    ws = gemm_workspace(A0.device)
+    rc = _lib.lib().rgn_gemm_bf16_qkv_pair(_p(A0), A0.stride(0), _p(W0), _p(b0), _p(out0), out0.stride(0), A0.shape[0], epi0,
+                                           _p(A1), A1.stride(0), _p(W1), _p(b1), _p(out1), out1.stride(0), A1.shape[0], epi1,
+                                           N, K, _p(ws), ws.numel() * 4, _stream())
+    _lib.check(rc, "rgn_gemm_bf16_qkv_pair")
+
+
 def gemv(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], silu_input: bool = False,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, K = x.shape

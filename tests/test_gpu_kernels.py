@@ -275,3 +275,97 @@ def test_attention_full_size_round_aware_vs_unsplit():
     q2 = q.clone()
     ops.attention(q2, k, vt, q2, S, H)
     assert torch.equal(q2, out)
+
+
+def _qkv_case(M, H, K, mlp, gen, kv_rows=None, skv=None, row_base=0):
+    """Random single-problem QKV(+MLP) projection inputs; returns everything both paths need."""
+    D = H * 128
+    N = 3 * D + mlp
+    A = bf(torch.randn(M, K, generator=gen)).cuda()
+    W = bf(0.05 * torch.randn(N, K, generator=gen)).cuda()
+    b = bf(0.1 * torch.randn(N, generator=gen)).cuda()
+    wq = bf(1 + 0.1 * torch.randn(128, generator=gen)).cuda()
+    wk = bf(1 + 0.1 * torch.randn(128, generator=gen)).cuda()
+    skv = skv or (row_base + M)
+    ang = torch.rand(max(skv, row_base + M), 64, generator=gen) * 6.28
+    cos = torch.repeat_interleave(torch.cos(ang), 2, dim=1).contiguous().cuda()
+    sin = torch.repeat_interleave(torch.sin(ang), 2, dim=1).contiguous().cuda()
+    return A, W, b, wq, wk, (cos, sin), D, N, skv
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("M,H,K,mlp,gather,row_base", [(600, 2, 256, 1024, False, 0), (333, 2, 256, 0, True, 0),
+                                                       (512, 4, 512, 2048, False, 16), (200, 2, 256, 0, True, 24)])
+def test_gemm_qkv_fused_epilogue_bit_identical_to_separate_kernels(M, H, K, mlp, gather, row_base, variant, monkeypatch):
+    """rgn_gemm_bf16_qkv == rgn_gemm_bf16 followed by rgn_qk_norm_rope_store, bit for bit: Q (in place), the
+    GELU(mlp) columns, the K slab and the V^T slab - identity rows, gathered cache rows (region step) and a
+    problem that starts at a joint-sequence offset that is / is not a multiple of 16."""
+    from regione_amd import ops
+    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    gen = torch.Generator().manual_seed(M + H)
+    skv = row_base + (M if not gather else 3 * M)
+    A, W, b, wq, wk, rope, D, N, skv = _qkv_case(M, H, K, mlp, gen, skv=skv, row_base=row_base)
+    kv_rows = None
+    if gather:                                     # joint rows -> scattered cache rows (ascending, like edited ids)
+        kv_rows = torch.cat([torch.arange(row_base), row_base + torch.randperm(skv - row_base, generator=gen)[:M].sort().values]).cuda()
+    skv_pad = ops.padded(skv)
+
+    def slabs():
+        return (torch.zeros(skv_pad, D, dtype=torch.bfloat16, device="cuda"), torch.zeros(D, skv_pad, dtype=torch.bfloat16, device="cuda"))
+    # separate kernels: `wide` holds the joint sequence, this problem's rows start at row_base
+    wide = torch.zeros(row_base + M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, W, b, wide[row_base:], epilogue=ops.EPI_GELU, gelu_from_col=3 * D)
+    k0, v0 = slabs()
+    ops.qk_norm_rope_store(wide, 0, D, 2 * D, H, wq, wk, rope, rope, k0, v0, kv_rows)
+    # fused
+    out = torch.zeros(row_base + M, N, dtype=torch.bfloat16, device="cuda")
+    k1, v1 = slabs()
+    epi = ops.qkv_epilogue(wq=wq, wk=wk, rope_q=rope, rope_k=rope, k_slab=k1, vt_slab=v1, H=H, k_col=0, v_col=D, q_col=2 * D,
+                           kv_rows=kv_rows, row_base=row_base)
+    ops.gemm_qkv(A, W, b, out[row_base:], epi, gelu_from_col=3 * D)
+    torch.cuda.synchronize()
+    assert torch.equal(out[row_base:, 2 * D:], wide[row_base:, 2 * D:])         # Q and GELU(mlp)
+    rows = (kv_rows[row_base:] if kv_rows is not None else torch.arange(row_base, row_base + M, device="cuda"))
+    assert torch.equal(k1[rows], k0[rows])
+    pos = ((rows & ~12) | ((rows & 4) << 1) | ((rows & 8) >> 1))
+    assert torch.equal(v1[:, pos], v0[:, pos])
+    k1[rows] = 0
+    v1[:, pos] = 0
+    assert not k1.any() and not v1.any()                                        # nothing outside this problem's cache rows
+    assert not out[:, :2 * D].any() and not out[:row_base].any()                # K / V columns are not written to C
+
+
+def test_gemm_qkv_pair_and_full_size_split_path():
+    """(a) text + image problems of a double block in one launch (row_base = T for the image stream, separate norm
+    weights); (b) the FLUX single-block shape (M = 8704, N = 21504): remainder tiles take the split-K + reduce path."""
+    from regione_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    H, K, T, Mi = 2, 256, 48, 400
+    D, N = H * 128, 3 * H * 128
+    Ai, W0, b0, wq0, wk0, rope, _, _, _ = _qkv_case(Mi, H, K, 0, gen, skv=T + Mi)
+    At, W1, b1, wq1, wk1, _, _, _, _ = _qkv_case(T, H, K, 0, gen)
+    skv_pad = ops.padded(T + Mi)
+    wide = torch.zeros(T + Mi, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_pair(Ai, W0, b0, wide[T:], At, W1, b1, wide[:T])
+    k0 = torch.zeros(skv_pad, D, dtype=torch.bfloat16, device="cuda"); v0 = torch.zeros(D, skv_pad, dtype=torch.bfloat16, device="cuda")
+    ops.qk_norm_rope_store(wide, 0, D, 2 * D, H, wq0, wk0, rope, rope, k0, v0, None, split_row=T, wq0=wq1, wk0=wk1)
+    out = torch.zeros_like(wide)
+    k1, v1 = torch.zeros_like(k0), torch.zeros_like(v0)
+    common = dict(rope_q=rope, rope_k=rope, k_slab=k1, vt_slab=v1, H=H, k_col=0, v_col=D, q_col=2 * D)
+    ops.gemm_qkv_pair(Ai, W0, b0, out[T:], ops.qkv_epilogue(wq=wq0, wk=wk0, row_base=T, **common),
+                      At, W1, b1, out[:T], ops.qkv_epilogue(wq=wq1, wk=wk1, row_base=0, **common))
+    assert torch.equal(out[:, 2 * D:], wide[:, 2 * D:]) and torch.equal(k1, k0) and torch.equal(v1, v0)
+    # (b) full size
+    H, K, M = 24, 3072, 8704
+    D = H * 128
+    A, W, b, wq, wk, rope, D, N, skv = _qkv_case(M, H, K, 4 * D, gen)
+    skv_pad = ops.padded(M)
+    wide = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(A, W, b, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * D)
+    k0 = torch.zeros(skv_pad, D, dtype=torch.bfloat16, device="cuda"); v0 = torch.zeros(D, skv_pad, dtype=torch.bfloat16, device="cuda")
+    ops.qk_norm_rope_store(wide, 0, D, 2 * D, H, wq, wk, rope, rope, k0, v0)
+    out = torch.empty_like(wide)
+    k1, v1 = torch.zeros_like(k0), torch.zeros_like(v0)
+    ops.gemm_qkv(A, W, b, out, ops.qkv_epilogue(wq=wq, wk=wk, rope_q=rope, rope_k=rope, k_slab=k1, vt_slab=v1, H=H, k_col=0,
+                                                v_col=D, q_col=2 * D), gelu_from_col=3 * D)
+    assert torch.equal(out[:, 2 * D:], wide[:, 2 * D:]) and torch.equal(k1, k0) and torch.equal(v1, v0)
