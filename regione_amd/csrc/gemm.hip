@@ -403,12 +403,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 1 : 2) void gemm_bf1
             uint16_t v[8];
             *(uint4*)v = *(const uint4*)(ct + row * CT_LD + vc * 8);
             uint16_t* dst = g.C + orow * g.ldc + ncol;
-            if (false) {
-            } else if (EPI == RGN_EPI_QKV) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));
-            } else if (EPI == RGN_EPI_GELU) {
+            if (EPI == RGN_EPI_GELU || EPI == RGN_EPI_QKV) {          // QKV: the fused MLP half of a single-stream block
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (ncol + e >= g.gelu_from_col) v[e] = f2bf(gelu_tanh(bf2f(v[e])));

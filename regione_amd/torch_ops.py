@@ -1,0 +1,113 @@
+"""`torch.ops.regione_mi.*` - the hot-path ops registered as PyTorch custom ops.
+
+SURVEY.md section 8(b) names this surface ("exposed to Python through PyTorch-ROCm custom ops"): the same
+entry points of libregione_hip.so that `regione_amd.ops` calls through ctypes, registered with
+`torch.library` so that they are dispatcher-visible (`torch.ops.regione_mi.arp_partition(...)`), carry
+schemas with their mutation annotations (`Tensor(a!)`), and have fake (meta) implementations for tracing.
+The native boundary stays the C ABI of include/regione_hip.h; nothing here computes - every op forwards to
+the HIP library and raises if it is missing (no CPU fallback).
+
+    import regione_amd.torch_ops            # registers the ops (idempotent)
+    e, u, mask = torch.ops.regione_mi.arp_partition(sample, v, cond, dt_final, 0.88, 64, 64, True)
+
+| op | replaces (reference file:line) |
+|---|---|
+| arp_partition        | token_selector + the one-step estimate, FluxKontext/utils.py:282-354, inplace.py:650-651 |
+| gather_rows          | ids_gather, utils.py:260-279 |
+| scatter_rows_        | ids_scatter, utils.py:240-257 |
+| split_euler_step     | scheduler update incl. the split update of partition / refresh steps, inplace.py:648-680 |
+| avd_apply            | `cache = ids_gather(cache, ids); noise_pred = cache * ratio`, inplace.py:315-318 |
+| cfg_combine          | inplace.py:364; Step1XEdit/inplace.py:401-410; QwenImageEdit/inplace.py:401-405 |
+| kv_partial_update_   | `_partially_linear` x2 + norm_k + RoPE into the K / V^T caches, inplace.py:734-794, fused_kernels.py:81-101 |
+| region_attention     | flash_attn_func / SDPA of the edited-token queries against the full cache, inplace.py:796-806 |
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+
+NS = "regione_mi"
+_lib = torch.library.Library(NS, "FRAGMENT")   # (the dispatcher omits trailing arguments that equal their schema default:
+# every implementation below therefore repeats the defaults)
+_defined = set()
+
+
+def _define(name: str, schema: str, impl, fake):
+    if name in _defined:
+        return
+    _lib.define(f"{name}{schema}")
+    torch.library.impl(_lib, name, "CUDA")(impl)
+    torch.library.register_fake(f"{NS}::{name}")(fake)
+    _defined.add(name)
+
+
+# ---- region ops ---------------------------------------------------------------------------------
+def _arp(sample, model_output, cond, dt_final, threshold, h_tok, w_tok, erosion_dilation=True):
+    e, u, mask, _, _ = ops.arp_partition(sample, model_output, cond, dt_final, threshold, h_tok, w_tok, erosion_dilation)
+    return e, u, mask
+
+
+def _arp_fake(sample, model_output, cond, dt_final, threshold, h_tok, w_tok, erosion_dilation=True):
+    L = h_tok * w_tok
+    k = torch.library.get_ctx().new_dynamic_size()          # K_e is data dependent
+    return (sample.new_empty((1, k), dtype=torch.int64), sample.new_empty((1, L - k), dtype=torch.int64),
+            sample.new_empty((L,), dtype=torch.uint8))
+
+
+_define("arp_partition",
+        "(Tensor sample, Tensor? model_output, Tensor cond, float dt_final, float threshold, int h_tok, int w_tok, "
+        "bool erosion_dilation=True) -> (Tensor, Tensor, Tensor)", _arp, _arp_fake)
+
+_define("gather_rows", "(Tensor x, Tensor ids) -> Tensor", ops.gather_rows,
+        lambda x, ids: x.new_empty((1, ids.numel(), x.shape[-1]) if x.dim() == 3 else (ids.numel(), x.shape[-1])))
+
+
+def _scatter(src, ids, dst):
+    ops.scatter_rows_(src, ids, dst)
+
+
+_define("scatter_rows_", "(Tensor src, Tensor ids, Tensor(a!) dst) -> ()", _scatter, lambda src, ids, dst: None)
+
+_define("split_euler_step", "(Tensor sample, Tensor v, float dt, Tensor? mask=None, float dt_direct=0.0) -> Tensor",
+        lambda sample, v, dt, mask=None, dt_direct=0.0: ops.euler_step(sample, v, dt, mask, dt_direct),
+        lambda sample, v, dt, mask=None, dt_direct=0.0: torch.empty_like(v))
+
+_define("avd_apply", "(Tensor cache, float ratio, Tensor? ids=None, bool round_ratio=False) -> Tensor",
+        lambda cache, ratio, ids=None, round_ratio=False: ops.avd_apply(cache, ratio, ids, round_ratio),
+        lambda cache, ratio, ids=None, round_ratio=False: (
+            torch.empty_like(cache) if ids is None else
+            cache.new_empty((1, ids.numel(), cache.shape[-1]) if cache.dim() == 3 else (ids.numel(), cache.shape[-1]))))
+
+_define("cfg_combine", "(Tensor pos, Tensor neg, float scale, int mode=0, float power=0.4) -> Tensor",
+        lambda pos, neg, scale, mode=0, power=0.4: ops.cfg_combine(pos, neg, scale, mode, power),
+        lambda pos, neg, scale, mode=0, power=0.4: torch.empty_like(pos))
+
+
+# ---- Region-Instruction KV cache ------------------------------------------------------------------
+def _kv_update(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base=0, eps=1e-6):
+    d = heads * 128
+    epi = ops.qkv_epilogue(wq=norm_q, wk=norm_k, rope_q=(cos_q, sin_q), rope_k=(cos_k, sin_k), k_slab=k_cache,
+                           vt_slab=vt_cache, H=heads, k_col=0, v_col=d, q_col=2 * d, kv_rows=kv_rows, row_base=row_base, eps=eps)
+    ops.gemm_qkv(x, w_kvq, b_kvq, q_out, epi, gelu_from_col=3 * d)
+
+
+_define("kv_partial_update_",
+        "(Tensor x, Tensor w_kvq, Tensor? b_kvq, Tensor(a!) q_out, Tensor norm_q, Tensor norm_k, Tensor cos_q, Tensor sin_q, "
+        "Tensor cos_k, Tensor sin_k, Tensor? kv_rows, Tensor(b!) k_cache, Tensor(c!) vt_cache, int heads, int row_base=0, "
+        "float eps=1e-6) -> ()", _kv_update, lambda *a, **k: None)
+
+
+def _region_attention(q, k_cache, vt_cache, out, skv, heads, scale=-1.0):
+    ops.attention(q, k_cache, vt_cache, out, skv, heads, scale if scale > 0 else None)
+
+
+_define("region_attention",
+        "(Tensor q, Tensor k_cache, Tensor vt_cache, Tensor(a!) out, int skv, int heads, float scale=-1.0) -> ()",
+        _region_attention, lambda *a, **k: None)
+
+
+def registered() -> Tuple[str, ...]:
+    return tuple(sorted(_defined))

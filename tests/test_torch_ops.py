@@ -1,0 +1,84 @@
+"""`torch.ops.regione_mi.*` (regione_amd/torch_ops.py): dispatcher-visible registration of the hot-path ops.
+CPU: schemas / mutation annotations / fake kernels (no compute).  GPU: each op equals the ctypes wrapper."""
+import pytest
+import torch
+
+import regione_amd.torch_ops as T
+
+
+def test_ops_are_registered_with_schemas():
+    assert set(T.registered()) == {"arp_partition", "gather_rows", "scatter_rows_", "split_euler_step", "avd_apply",
+                                   "cfg_combine", "kv_partial_update_", "region_attention"}
+    s = str(torch.ops.regione_mi.scatter_rows_.default._schema)
+    assert "Tensor(a!) dst" in s
+    s = str(torch.ops.regione_mi.kv_partial_update_.default._schema)
+    assert "Tensor(b!) k_cache" in s and "Tensor(c!) vt_cache" in s
+
+
+def test_fake_kernels_give_shapes_without_a_gpu():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        x = torch.empty(1, 4096, 64, dtype=torch.bfloat16, device="cuda")
+        ids = torch.empty(1, 1000, dtype=torch.int64, device="cuda")
+        assert torch.ops.regione_mi.gather_rows(x, ids).shape == (1, 1000, 64)
+        assert torch.ops.regione_mi.avd_apply(x, 1.01, ids).shape == (1, 1000, 64)
+        assert torch.ops.regione_mi.split_euler_step(x.float(), x, -0.03).dtype == torch.bfloat16
+        assert torch.ops.regione_mi.cfg_combine(x, x, 6.0, 1).shape == x.shape
+
+
+def test_no_cpu_kernels_are_registered():
+    """The ops exist for CUDA (HIP) tensors only: a CPU tensor must fail loudly, not fall back."""
+    x = torch.zeros(1, 8, 64)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.regione_mi.gather_rows(x, torch.zeros(1, 2, dtype=torch.int64))
+
+
+@pytest.mark.gpu
+def test_torch_ops_equal_ctypes_wrappers():
+    from regione_amd import ops, synth
+    h = w = 32
+    L = h * w
+    g = torch.Generator().manual_seed(0)
+    cond = torch.randn(1, L, 64, generator=g).bfloat16().cuda()
+    sample = torch.randn(1, L, 64, generator=g).cuda()
+    tgt = synth.region_target(h, w, (8, 20, 6, 22), cond.cpu(), seed=7, ramp=0.9).cuda()
+    v = ((tgt[None] - sample) / -0.7).bfloat16()
+    e, u, mask = torch.ops.regione_mi.arp_partition(sample, v, cond, -0.7, 0.88, h, w, True)
+    e2, u2, mask2, _, _ = ops.arp_partition(sample, v, cond, -0.7, 0.88, h, w, True)
+    assert torch.equal(e, e2) and torch.equal(u, u2) and torch.equal(mask, mask2) and 0 < e.numel() < L
+    got = torch.ops.regione_mi.gather_rows(cond, e)
+    assert torch.equal(got, ops.gather_rows(cond, e))
+    dst, dst2 = torch.zeros_like(cond), torch.zeros_like(cond)
+    torch.ops.regione_mi.scatter_rows_(got, e, dst)
+    ops.scatter_rows_(got, e, dst2)
+    assert torch.equal(dst, dst2) and dst.any()
+    assert torch.equal(torch.ops.regione_mi.split_euler_step(sample, v, -0.03, mask, -0.5), ops.euler_step(sample, v, -0.03, mask, -0.5))
+    assert torch.equal(torch.ops.regione_mi.avd_apply(v, 1.0173, e), ops.avd_apply(v, 1.0173, e))
+    assert torch.equal(torch.ops.regione_mi.cfg_combine(v, cond, 6.0, 1, 0.4), ops.cfg_combine(v, cond, 6.0, 1, 0.4))
+    # Region-Instruction KV cache: partial update of K / V^T for the edited rows + attention of those rows
+    H, K = 2, 256
+    d = H * 128
+    T_ = 32
+    M = T_ + e.numel()
+    skv = T_ + 2 * L
+    x = (0.5 * torch.randn(M, K, generator=g)).bfloat16().cuda()
+    W = (0.05 * torch.randn(3 * d, K, generator=g)).bfloat16().cuda()
+    b = (0.1 * torch.randn(3 * d, generator=g)).bfloat16().cuda()
+    nq, nk = torch.ones(128).bfloat16().cuda(), torch.ones(128).bfloat16().cuda()
+    ang = torch.rand(skv, 64, generator=g) * 6.28
+    cos = torch.repeat_interleave(torch.cos(ang), 2, 1).contiguous().cuda()
+    sin = torch.repeat_interleave(torch.sin(ang), 2, 1).contiguous().cuda()
+    kv_rows = torch.cat([torch.arange(T_, device="cuda"), T_ + e.squeeze(0)])
+    skv_pad = ops.padded(skv)
+    kc = [torch.zeros(skv_pad, d, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    vc = [torch.zeros(d, skv_pad, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    q = [torch.zeros(M, 3 * d, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    cq, sq = cos[kv_rows].contiguous(), sin[kv_rows].contiguous()
+    torch.ops.regione_mi.kv_partial_update_(x, W, b, q[0], nq, nk, cq, sq, cos, sin, kv_rows, kc[0], vc[0], H)
+    ops.gemm(x, W, b, q[1])
+    ops.qk_norm_rope_store(q[1], 0, d, 2 * d, H, nq, nk, (cq, sq), (cos, sin), kc[1], vc[1], kv_rows)
+    assert torch.equal(kc[0], kc[1]) and torch.equal(vc[0], vc[1]) and torch.equal(q[0][:, 2 * d:], q[1][:, 2 * d:])
+    o0, o1 = torch.empty(M, d, dtype=torch.bfloat16, device="cuda"), torch.empty(M, d, dtype=torch.bfloat16, device="cuda")
+    torch.ops.regione_mi.region_attention(q[0][:, 2 * d:], kc[0], vc[0], o0, skv, H)
+    ops.attention(q[1][:, 2 * d:], kc[1], vc[1], o1, skv, H)
+    assert torch.equal(o0, o1) and torch.isfinite(o0.float()).all()
