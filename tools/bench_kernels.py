@@ -37,7 +37,10 @@ def bench_gemm():
               ("double txt qkv", 512, 9216, 3072), ("double txt ff2", 512, 3072, 12288),
               ("region kvq+mlp", 1536, 21504, 3072), ("region proj_out", 1536, 3072, 15360),
               ("region img out", 1024, 3072, 3072), ("square 8192", 8192, 8192, 8192)]
+    only = os.environ.get("GEMM_ONLY")
     for name, M, N, K in shapes:
+        if only and only not in name:
+            continue
         A, W, b = rnd(M, K), rnd(N, K) * 0.05, rnd(N)
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         for variant in VARIANTS:
@@ -45,6 +48,9 @@ def bench_gemm():
             med, best = timeit(lambda: ops.gemm(A, W, b, out))
             fl = 2.0 * M * N * K
             print(f"gemm[{variant:>4}] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
+        if os.environ.get("GEMM_VENDOR"):      # reference point only: the vendor library (hipBLASLt via torch), bias epilogue
+            med, best = timeit(lambda: torch.addmm(b, A, W.t(), out=out))
+            print(f"gemm[ lib] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
         del A, W, out
 
 
