@@ -125,9 +125,7 @@ struct GemmGroup {
 };
 
 constexpr int MODE_FULL = 0, MODE_PARTIAL = 1, MODE_REDUCE = 2;
-#ifndef RGN_ABL
-#define RGN_ABL 0      // developer ablations of the 4-wave loop (wrong results): 1 no barrier, 2 no DMA, 3 MFMA only
-#endif
+
 
 // Tile configurations:
 //   <128,128,2,2>: 4 waves, wave tile 64x64, 64 KiB LDS, 2 blocks/CU  - small / ragged problems
@@ -224,79 +222,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
         k_begin = split * per;
         nk = max(0, min(per, nk_all - k_begin));
     }
-    if constexpr (NW == 4 && BM == 256) { if (MODE != MODE_REDUCE && nk > 0) {
-        // ---- 4 waves x (128 x 128) wave tiles, one wave per SIMD, accumulators in the 256 AGPRs --------------
-        // Nothing hides a stall here, so the loop is software pipelined: the fragments of the NEXT k-half are read
-        // from LDS (and the next K tile's DMA is issued) while the 64 MFMAs of the current k-half run; the sched
-        // group barriers pin the interleave (4 MFMA : 1 ds_read : 1 DMA piece).
-        // Registers: A fragments roll (af[i] is re-read for the next k-half as soon as row i's MFMAs have issued),
-        // B fragments are double buffered.  LDS: tile kt lives in buffer kt & 1; the DMA of tile kt+2 is issued during
-        // the second k-half of tile kt (all reads of tile kt are behind the barrier by then) and has two phases to land.
-        //   phase A: MFMA(kt, kk=0) | ds_read (kt, kk=1)          -> vmcnt(0) ; barrier
-        //   phase B: MFMA(kt, kk=1) | ds_read (kt+1, kk=0) | DMA of tile kt+2 into buffer kt & 1
-        // Tiles past the end are clamped to the last one (harmless re-stage), so the body is branch free.
-        bf8_t af[2][TM], bfr[2][TN];
-        static_assert(TM == 8 && TN == 8 && PA == 8 && PB == 8, "4-wave schedule is written for 128x128 wave tiles");
-        // MFMA through inline asm: "+a" pins the 64 accumulator fragments to the 256 AGPRs (left to itself the register
-        // allocator mixes VGPR- and AGPR-form MFMAs here and glues them with hundreds of v_accvgpr copies per iteration),
-        // and volatile keeps the MFMA order; the compiler still tracks the LDS reads feeding them (s_waitcnt placement).
-#define RGN_MFMA(ACC, B8, A8) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(B8), "v"(A8))
-        auto dma_piece = [&](int kt, int buf, int q) {          // q in [0, 16): 8 A pieces then 8 B pieces of this wave
-            uint8_t* base = smem + buf * STAGE;
-            if (q < PA)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(a_src[q] + (size_t)kt * (BK * 2)),
-                                                 (lds_ptr_t)(base + (wave * PA + q) * 1024), 16, 0, 0);
-            else
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(b_src[q - PA] + (size_t)kt * (BK * 2)),
-                                                 (lds_ptr_t)(base + A_BYTES + (wave * PB + (q - PA)) * 1024), 16, 0, 0);
-        };
-        const int last = k_begin + nk - 1;
-        stage(k_begin, 0);
-        stage(min(k_begin + 1, last), 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[0][j] = *(const bf8_t*)(smem + b_off[0] + j * 2048);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *(const bf8_t*)(smem + a_off[0] + i * 2048);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const uint8_t* sb = smem + cur * STAGE;
-            const uint8_t* sn = smem + (cur ^ 1) * STAGE;
-            // ---- phase A: MFMA (kt, kk = 0) | reads of (kt, kk = 1) ---------------------------------------------
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#if RGN_ABL != 3
-                bfr[1][i] = *(const bf8_t*)(sb + b_off[1] + i * 2048);
-                af[1][i] = *(const bf8_t*)(sb + a_off[1] + i * 2048);
-#endif
-#pragma unroll
-                for (int j = 0; j < TN; ++j) RGN_MFMA(acc[i][j], bfr[0][j], af[0][i]);
-            }
-#if RGN_ABL != 1
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-#endif
-            // ---- phase B: MFMA (kt, kk = 1) | reads of (kt + 1, kk = 0) | DMA of tile kt + 2 ---------------------
-            const int kt2 = min(k_begin + kt + 2, last);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#if RGN_ABL != 3
-                bfr[0][i] = *(const bf8_t*)(sn + b_off[0] + i * 2048);
-                af[0][i] = *(const bf8_t*)(sn + a_off[0] + i * 2048);
-#endif
-#if RGN_ABL != 2 && RGN_ABL != 3
-                dma_piece(kt2, cur, 2 * i);
-                dma_piece(kt2, cur, 2 * i + 1);
-#endif
-#pragma unroll
-                for (int j = 0; j < TN; ++j) RGN_MFMA(acc[i][j], bfr[1][j], af[1][i]);
-            }
-        }
-#undef RGN_MFMA
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(0)" ::: "memory");     // MFMA results settled; clamped re-stages drained
-        __syncthreads();
-    } } else if (MODE != MODE_REDUCE && nk > 0) {
+    if (MODE != MODE_REDUCE && nk > 0) {
         stage(k_begin, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -682,21 +608,13 @@ static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, voi
     gg.ws = (float*)ws;
     gg.nsplit = 1;
     int rc;
-    // whole rounds of 256x256 tiles run on the 4-wave / 128x128-wave-tile kernel (software-pipelined, AGPR accumulators);
-    // remainders, split-K partials and small launches stay on the 8-wave kernel, which tolerates latency better
-    const char* v4 = getenv("RGN_GEMM_4W");
-    const bool four = (BM == 256 && WN == 4) && !(v4 && v4[0] == '0');
-    auto full_launch = [&](int count) {
-        if (four && count >= 256) return launch_gemm<BM, BN, 2, 2, MODE_FULL>(gg, epilogue, st);
-        return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
-    };
     if (nsplit == 1) {
         gg.tile_offset = 0; gg.nt_launch = nt;
-        return full_launch(nt);
+        return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
     }
     if (full > 0) {
         gg.tile_offset = 0; gg.nt_launch = full;
-        if ((rc = full_launch(full))) return rc;
+        if ((rc = launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st))) return rc;
     }
     gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = nsplit;
     if ((rc = launch_gemm<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, st))) return rc;
@@ -718,12 +636,11 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
     bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < 0.92f * e128);
     const char* v = getenv("RGN_GEMM_VARIANT");
     if (v && v[0] == '1') use_big = false;
-    if (v && (v[0] == '2' || v[0] == '3')) use_big = true;
+    if (v && v[0] == '2') use_big = true;
     const int b = use_big ? 256 : 128;
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
     if (gg.nt == 0) return 0;
-    if (use_big && v && v[0] == '3') return gemm_schedule<256, 256, 2, 2>(gg, epilogue, 256, p256.nsplit, ws, st);   // experiment: 4 waves, 128x128 wave tiles
     return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, p256.nsplit, ws, st)
                    : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, split128(gg.nt, K, ws != nullptr, ws_bytes), ws, st);
 }
