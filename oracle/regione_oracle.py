@@ -147,9 +147,11 @@ class RegionState:
     refresh_step_real_time: List[int] = field(default_factory=list)
 
     def set_parameters(self, num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16",
-                       threshold=0.93, cache_threshold=0.04, erosion_dilation=True):
-        """utils.py:390-402."""
-        assert warmup_step >= 1 and num_inference_steps == 28, \
+                       threshold=0.93, cache_threshold=0.04, erosion_dilation=True, gamma=None):
+        """utils.py:390-402.  `gamma` (N-1 decay factors) is the product's documented extension for
+        num_inference_steps != 28; the reference itself asserts 28."""
+        self.gamma = None if gamma is None else torch.as_tensor(gamma, dtype=torch.float16)
+        assert warmup_step >= 1 and (num_inference_steps == 28 or self.gamma is not None), \
             "Changing the inference step requires fitting a new gamma"
         self.inference_step, self.warmup_step, self.post_step = num_inference_steps, warmup_step, post_step
         self.threshold, self.cache_threshold, self.erosion_dilation = threshold, cache_threshold, erosion_dilation
@@ -302,14 +304,14 @@ def avd_decide(st: RegionState, avd: AvdState, i: int, timesteps: torch.Tensor, 
 
 
 def derive_schedule(seq_len: int, family: str = "flux", warmup=6, post=2, refresh="16",
-                    cache_threshold=0.04, n=28) -> List[str]:
+                    cache_threshold=0.04, n=28, gamma=None) -> List[str]:
     """Data-independent step plan (quirk A-7): 'F' full, 'S' full+store K/V, 'R' region forward,
     'C' cache-served.  Simulates avd_decide + the refresh bookkeeping of scheduler_step/step."""
     st = RegionState()
-    st.set_parameters(n, warmup, post, refresh, 0.0, cache_threshold, True)
+    st.set_parameters(n, warmup, post, refresh, 0.0, cache_threshold, True, gamma=gamma)
     st.refresh(None, None, 0, 0, 0)
     _, ts = flow_match_schedule(n, seq_len)
-    gamma = torch.tensor(GAMMA[family], dtype=torch.float16)
+    gamma = torch.tensor(GAMMA[family], dtype=torch.float16) if gamma is None else st.gamma
     avd, plan = AvdState(), []
     for i in range(n):
         hit, _ = avd_decide(st, avd, i, ts, gamma)
@@ -602,7 +604,7 @@ def denoise(model_fn, st: RegionState, latents, image_latents, latent_ids, txt_l
     n = st.inference_step
     L = latents.shape[1]
     sigmas, timesteps = flow_match_schedule(n, L)
-    gamma = torch.tensor(GAMMA[family], dtype=torch.float16)
+    gamma = torch.tensor(GAMMA[family], dtype=torch.float16) if getattr(st, "gamma", None) is None else st.gamma
     st.refresh(image_latents, latent_ids, txt_length, h_tok, w_tok)
     if not regione:
         for i in range(n):

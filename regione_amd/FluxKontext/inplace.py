@@ -88,6 +88,8 @@ def avd_decide(M: FluxKontextManager, avd: AvdState, i: int, timesteps: torch.Te
     """inplace.py:295-313 on HOST tensors: gamma[i-1] is a 0-dim fp16 tensor, timesteps are fp32, so
     `ratio` is fp32 and `accumulate` is carried in fp32 - the same dtype path as the reference's
     device tensors, minus the two implicit device->host syncs per step (quirk A-7)."""
+    if getattr(M, "gamma", None) is not None:      # caller-provided table (extension, num_inference_steps != 28)
+        gamma = M.gamma
     ratio = None
     if M.current_step <= M.warmup_step or M.current_step > M.inference_step - M.post_step - 1 or \
             M.current_step == M.prev_refresh_step:

@@ -81,10 +81,17 @@ class FluxKontextManager:
         self.image_rotary_emb = None     # (cos, sin) for the FULL id table
         self.rope_q_region = None        # (cos, sin) rows of the compacted query set
         self.strict_reference = False    # share one K/V cache between CFG branches like the reference (A-4)
+        self.gamma = None                # caller-provided AVD decay table (extension: num_inference_steps != 28)
 
     def set_parameters(self, args) -> None:
-        assert args["warmup_step"] >= 1 and args["num_inference_steps"] == 28, \
+        # reference: `num_inference_steps == 28` always (utils.py:391, the shipped gamma tables have 27 entries).
+        # Extension: a caller that brings its own table (`gamma`, N-1 entries; tools/fit_gamma.py fits one) may use N != 28.
+        self.gamma = args.get("gamma")
+        assert args["warmup_step"] >= 1 and (args["num_inference_steps"] == 28 or self.gamma is not None), \
             "Changing the inference step requires fitting a new gamma"
+        if self.gamma is not None:
+            self.gamma = torch.as_tensor(self.gamma, dtype=torch.float16).cpu()
+            assert self.gamma.numel() == args["num_inference_steps"] - 1, "gamma must have num_inference_steps - 1 entries"
         self.inference_step = args["num_inference_steps"]
         self.warmup_step = args["warmup_step"]
         self.post_step = args["post_step"]

@@ -26,6 +26,21 @@ _FAMILY = {
 }
 
 
+def resample_gamma(table, num_inference_steps: int):
+    """Linear re-sampling of a fitted 27-entry decay table to `num_inference_steps - 1` entries over the same
+    normalised step axis, in fp16 like the shipped tables (extension; a table fitted at the target step count with
+    tools/fit_gamma.py is the principled choice).  gamma_i scales the velocity over ONE step, so the per-step decay is
+    re-expressed per unit of normalised time: g' = g ** (27 / (N - 1))."""
+    import torch
+    g = torch.as_tensor(table, dtype=torch.float64)
+    n_old, n_new = g.numel(), num_inference_steps - 1
+    x_new = torch.linspace(0, n_old - 1, n_new, dtype=torch.float64)
+    lo = x_new.floor().long().clamp(max=n_old - 2)
+    w = x_new - lo
+    interp = g[lo] * (1 - w) + g[lo + 1] * w
+    return (interp ** (n_old / n_new)).to(torch.float16)
+
+
 class RegionEHelper(object):
     def __init__(self, pipeline=None):
         if pipeline is not None:
@@ -50,8 +65,17 @@ class RegionEHelper(object):
         self.pipeline = self._family().unwarp_modules(self.pipeline)
 
     def set_params(self, num_inference_steps=28, warmup_step=None, post_step=None, refresh_step=None, threshold=None,
-                   cache_threshold=None, erosion_dilation=None, strict_reference=None):
-        assert num_inference_steps == 28, "num_inference_steps must be 28"
+                   cache_threshold=None, erosion_dilation=None, strict_reference=None, gamma=None):
+        # reference: 28 steps only (tool/RegionE.py:44).  Extension: `gamma` = N-1 fitted decay factors (list / tensor,
+        # e.g. from tools/fit_gamma.py) or "resample" (the family's 27-entry table linearly re-sampled to N-1 entries,
+        # SURVEY.md section 8d config 5) lifts the restriction.
+        assert num_inference_steps == 28 or gamma is not None, "num_inference_steps must be 28"
+        if gamma is not None:
+            if isinstance(gamma, str):
+                assert gamma == "resample"
+                gamma = resample_gamma(self._family().gamma, num_inference_steps)
+            self.config['num_inference_steps'] = num_inference_steps
+            self.config['gamma'] = gamma
         if warmup_step is not None: self.config['warmup_step'] = warmup_step
         if post_step is not None: self.config['post_step'] = post_step
         if refresh_step is not None: self.config['refresh_step'] = refresh_step

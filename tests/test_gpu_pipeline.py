@@ -313,3 +313,46 @@ def test_qwen_loop_fixture_on_gpu(golden, name):
     assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
     assert torch.equal(pipe._regione_manager.edited_ids.cpu().squeeze(0).int(), g["edited_ids"].squeeze(0))
     assert O.psnr(out.cpu(), g["final"]) > (50.0 if g["bf16"] else 110.0)      # row-norm reduction order (CFG mode 2)
+
+
+def test_fit_gamma_tool_and_non_28_step_run_on_gpu():
+    """tools/fit_gamma.py on the toy engine at N = 20 -> a 19-entry table -> RegionE with num_inference_steps = 20
+    (extension) runs, caches at least one step, and matches the oracle loop driven by the same table (ids exact,
+    latents >= 40 dB)."""
+    from tools.fit_gamma import fit
+    cfg = synth.FluxConfig(**synth.TOY)
+    h = w = 16
+    T, N = 32, 20
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+    pipe = _toy_pipe({k: v.cuda() for k, v in wts.items()}, cfg)
+
+    def call(seed):
+        lat, img, prompt, pooled = [t.cuda() for t in synth.make_edit_inputs(h, w, T, cfg, seed=50 + seed)]
+        pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=h * 16, width=w * 16, latents=lat,
+             num_inference_steps=N, return_dict=False)
+    gamma, ratio = fit(pipe, call, N, samples=2)
+    assert gamma.shape == (N - 1,) and gamma.dtype == torch.float16 and torch.isfinite(gamma.float()).all()
+    lat, img, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=9, dtype=torch.bfloat16)
+    helper = RegionEHelper(pipe)
+    kw = dict(warmup_step=4, post_step=2, refresh_step="10", threshold=0.1, cache_threshold=0.5)
+    helper.set_params(num_inference_steps=N, gamma=gamma, **kw)
+    helper.enable()
+    trace = {}
+    out = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(), height=h * 16, width=w * 16,
+               latents=lat.cuda(), num_inference_steps=N, return_dict=False, trace=trace)[0].cpu()
+    st = O.RegionState()
+    st.set_parameters(N, 4, 2, "10", 0.1, 0.5, True, gamma=gamma)
+    ocfg = O.FluxCfg(**synth.TOY)
+    caches = [O.KVCache() for _ in range(cfg.n_layers)]
+    txt_ids = torch.zeros(T, 3)
+
+    def model(x, t, img_ids):
+        ts = t.expand(x.shape[0]).to(x.dtype)
+        guidance = torch.full([1], 2.5, dtype=torch.float32).expand(x.shape[0])
+        return O.transformer_forward(wts, ocfg, st, caches, x, prompt, pooled, ts / 1000, img_ids, txt_ids, guidance)
+    tr = {}
+    with torch.no_grad():
+        ref = O.denoise(model, st, lat, img, synth.flux_latent_ids(h, w), T, h, w, trace=tr)
+    assert len(trace["kind"]) == N and "".join(trace["kind"]) == "".join(tr["kind"])
+    assert torch.equal(pipe._regione_manager.edited_ids.cpu(), st.edited_ids)
+    assert O.psnr(out, ref) >= 40.0

@@ -307,3 +307,42 @@ def test_family_gamma_tables_match_reference_fixture(golden):
                      ("QwenImageEdit", "gamma_qwen"), ("QwenImageEditPlus", "gamma_qwen_plus")):
         mod = importlib.import_module(f"regione_amd.{fam}.inplace")
         assert mod.gamma.dtype == torch.float16 and torch.equal(mod.gamma, g[key]), fam
+
+
+def test_num_inference_steps_extension_with_caller_gamma(golden, cpu_ops):
+    """Extension: N != 28 is accepted only together with a decay table of N-1
+    entries; the default behaviour (assert 28, tool/RegionE.py:44, utils.py:391) is untouched.  The N = 50 loop of the
+    patched pipeline equals the oracle's loop with the same table, bit for bit, plan included."""
+    from regione_amd.tool.RegionE import resample_gamma
+    g = golden("loop_bf16_32")
+    h, w = g["h"], g["w"]
+    L = h * w
+    lat, img, _, _ = synth.make_edit_inputs(h, w, 8, synth.FluxConfig(), seed=g["seed"], dtype=torch.bfloat16)
+    tgt = synth.region_target(h, w, tuple(int(x) for x in g["box"]), img, seed=g["tseed"], ramp=g["ramp"])
+    pipe = H.FluxKontextPipeline(FakeTransformer(torch.cat([tgt, img[0].float()], 0), w, L))
+    helper = RegionEHelper(pipe)
+    with pytest.raises(AssertionError):
+        helper.set_params(num_inference_steps=50)
+    helper.set_params(num_inference_steps=50, gamma="resample", warmup_step=10, post_step=4, refresh_step="28",
+                      threshold=0.93, cache_threshold=0.04)
+    table = helper.config["gamma"]
+    assert table.dtype == torch.float16 and table.numel() == 49
+    assert torch.equal(resample_gamma(O.GAMMA["flux"], 28), torch.tensor(O.GAMMA["flux"], dtype=torch.float16))   # identity at N = 28
+    helper.enable()
+    trace = {}
+    out = pipe(image=img, prompt_embeds=torch.zeros(1, 8, 4), pooled_prompt_embeds=torch.zeros(1, 4), height=h * 16,
+               width=w * 16, latents=lat, num_inference_steps=50, return_dict=False, trace=trace)[0]
+    st = O.RegionState()
+    st.set_parameters(50, 10, 4, "28", 0.93, 0.04, True, gamma=table)
+    tr = {}
+
+    def fn(x, t, img_ids):
+        tok = (img_ids[:, 0] * L + img_ids[:, 1] * w + img_ids[:, 2]).long()
+        k = float(1.0 / (t.expand(x.shape[0]).to(x.dtype) / 1000).float()[0].item())
+        return ((x.float() - torch.cat([tgt, img[0].float()], 0)[tok[:x.shape[1]]][None]) * k).to(x.dtype)
+    ref = O.denoise(fn, st, lat, img, synth.flux_latent_ids(h, w), 8, h, w, trace=tr)
+    kinds = "".join(trace["kind"])
+    assert len(kinds) == 50 and kinds == "".join(tr["kind"]) and "C" in kinds and "R" in kinds
+    assert kinds == "".join(O.derive_schedule(L, "flux", 10, 4, "28", 0.04, n=50, gamma=table)).replace("S", "F")
+    assert torch.equal(pipe._regione_manager.edited_ids, st.edited_ids)
+    assert torch.equal(out, ref)

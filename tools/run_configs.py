@@ -60,7 +60,8 @@ def make_box(h_tok, w_tok, frac):
     return (r0, r0 + bs, c0, c0 + bs)
 
 
-def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, timed_edits=1, vanilla_runs=2):
+def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, timed_edits=1, vanilla_runs=2, steps=28,
+             helper_kw=None):
     from regione_amd.harness import flux as HF, step1x as HS, qwen as HQ
     h_tok = w_tok = size // 16
     L = h_tok * w_tok
@@ -90,12 +91,13 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
 
     helper = RegionEHelper(pipe)
     with contextlib.redirect_stdout(sys.stderr):
-        helper.set_params(**defaults)
+        helper.set_params(**dict(defaults, **(helper_kw or {})))
     cfgd = dict(helper.config) if hasattr(helper, "config") else {}
     box = make_box(h_tok, w_tok, frac)
 
     def edit(trace=None):
-        kw = dict(image=img, prompt_embeds=prompt, height=size, width=size, latents=lat, return_dict=False)
+        kw = dict(image=img, prompt_embeds=prompt, height=size, width=size, latents=lat, return_dict=False,
+                  num_inference_steps=steps)
         if trace is not None:
             kw["trace"] = trace
         if family == "flux":
@@ -129,11 +131,12 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
     want = expected_ids(h_tok, w_tok, box)
     kinds = "".join(trace["kind"])
     thr = cfgd.get("cache_threshold", {"flux": 0.04, "qwen": 0.03}.get(fam_key, 0.02))
-    plan = "".join(O.derive_schedule(L, fam_key, 6, 2, "16", thr)).replace("S", "F")
+    plan = "".join(O.derive_schedule(L, fam_key, cfgd.get("warmup_step", 6), cfgd.get("post_step", 2), cfgd.get("refresh_step", "16"),
+                                     thr, n=steps, gamma=cfgd.get("gamma"))).replace("S", "F")
     res = dict(case=name, family=family, size=size, L=L, T=T, T_neg=Tn, K_e=int(ids.numel()), edited_frac=ids.numel() / L,
                plan=kinds, plan_matches_reference_logic=(kinds == plan), ids_match_constructed_region=bool(torch.equal(ids, want)),
-               finite=bool(torch.isfinite(out.float()).all()), regione_edit_s=tr_s, regione_steps_per_s=28 / tr_s,
-               full_token_edit_s=tv, full_token_steps_per_s=28 / tv, speedup=tv / tr_s,
+               finite=bool(torch.isfinite(out.float()).all()), steps=steps, regione_edit_s=tr_s, regione_steps_per_s=steps / tr_s,
+               full_token_edit_s=tv, full_token_steps_per_s=steps / tv, speedup=tv / tr_s,
                psnr_vs_full_token_db=float(O.psnr(out.cpu(), van.cpu())), cfg_scale=cfg_scale,
                peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)
     helper.disable()
@@ -149,13 +152,18 @@ CASES = {
     "step1x_512": [("step1x_v1p1_512_cfg6 (configs[0] on the GPU)", "step1x", 512, 0.25, dict(cfg_scale=6.0))],
     "step1x_v1p2_2048": [("step1x_v1p2_2048_cfg6 bf16 28 steps (configs[4] shape; fp8 / 50 steps are later rows)", "step1x_v1p2",
                           2048, 0.25, dict(cfg_scale=6.0, Tn=384, vanilla_runs=1))],
+    "step1x_v1p2_2048_50": [("step1x_v1p2_2048_cfg6 bf16 50 steps, gamma re-sampled to 49 entries (configs[4]; fp8 weights are a later row)",
+                             "step1x_v1p2", 2048, 0.25,
+                             dict(cfg_scale=6.0, Tn=384, vanilla_runs=1, steps=50,
+                                  helper_kw=dict(num_inference_steps=50, gamma="resample", warmup_step=10, post_step=4,
+                                                 refresh_step="28", cache_threshold=0.02)))],
     "qwen_1024": [("qwen_image_edit_1024_cfg4 (configs[2])", "qwen", 1024, 0.25, dict(cfg_scale=4.0, Tn=384))],
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("cases", nargs="*", default=[c for c in CASES if c != "step1x_v1p2_2048_50"])
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     device = torch.device("cuda", 0)
