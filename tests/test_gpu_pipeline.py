@@ -356,3 +356,21 @@ def test_fit_gamma_tool_and_non_28_step_run_on_gpu():
     assert len(trace["kind"]) == N and "".join(trace["kind"]) == "".join(tr["kind"])
     assert torch.equal(pipe._regione_manager.edited_ids.cpu(), st.edited_ids)
     assert O.psnr(out, ref) >= 40.0
+
+
+def test_edit_driver_timing_protocol(tmp_path):
+    """tools/edit_driver.py: the reference drivers' protocol (jsonl items, 3 warm-ups, synchronised wall-clock per item,
+    time_consuming.json with the reference's keys) on the toy engine."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    items = tmp_path / "data.jsonl"
+    items.write_text("\n".join(json.dumps({"instruction": f"edit number {i}", "key": f"synthetic/item_{i}"}) for i in range(3)))
+    out = tmp_path / "result"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "edit_driver.py"), "--image_path", str(items), "--use_regione",
+                        "--compare", "--toy", "--size", "256", "--threshold", "0.1", "--erosion_dilation", "--output_dir", str(out)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.load(open(out / "time_consuming.json"))
+    assert rep["num_item"] == 3 and len(rep["time_consuming_list"]) == 3 and rep["ave_time_consuming"] > 0
+    assert set(rep["latent_psnr_vs_full_token_db"]) == {f"synthetic/item_{i}" for i in range(3)}
+    assert all(os.path.exists(out / f"item_{i}.latent.pt") for i in range(3))
