@@ -298,6 +298,7 @@ def main():
 
     for _ in range(args.warmup):
         out = edit()
+        D.gather_latents([out], [rank], world, dist)           # warm the collective too (communicator / channel setup)
     timer = KernelTimer()
     timer.wrap(ops)
 
