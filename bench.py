@@ -251,6 +251,8 @@ def main():
     ap.add_argument("--toy", action="store_true", help="toy model (debugging only; result is not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="debugging: 'gloo' lets several ranks share ONE GPU (with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="debugging: every rank uses cuda:0 (single-GPU box smoke of the multi-rank path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -260,10 +262,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from regione_amd import dist as D
-    dist = D.init("nccl", device) if world > 1 else None
+    dist = D.init(args.dist_backend, device) if world > 1 else None
 
     from regione_amd import RegionEHelper, synth, ops
     from oracle import regione_oracle as O            # checker / cpu_baseline leg only

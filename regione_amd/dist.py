@@ -47,8 +47,12 @@ def gather_latents(local: Sequence[torch.Tensor], image_ids: Sequence[int], n_im
     for slot in range(per):
         have = slot < len(local)
         mine = local[slot] if have else torch.zeros_like(local[0])
+        dev = mine.device
+        if dist.get_backend() == "gloo" and mine.is_cuda:      # debugging path: gloo collectives run on host tensors
+            mine = mine.cpu()
         bucket = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(bucket, mine.contiguous())
+        bucket = [b.to(dev) for b in bucket]
         for r in range(world):
             j = slot * world + r
             if j < n_images:
