@@ -567,7 +567,9 @@ static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes) {
         const float cost = full_cost + (float)rounds * (per * 1.45f + 5.0f) + 0.07f * (float)blocks + 10.0f;
         if (cost < p.cost_us) { p.cost_us = cost; p.nsplit = S; }
     }
-    if (base - p.cost_us < fmaxf(30.0f, 0.05f * base)) { p.nsplit = 1; p.cost_us = base; }   // not worth two extra launches
+    static const float min_gain = [] { const char* e = getenv("RGN_GEMM_SPLIT_MIN_US"); return e ? (float)atof(e) : 30.0f; }();
+    static const float min_frac = [] { const char* e = getenv("RGN_GEMM_SPLIT_MIN_FRAC"); return e ? (float)atof(e) : 0.05f; }();
+    if (base - p.cost_us < fmaxf(min_gain, min_frac * base)) { p.nsplit = 1; p.cost_us = base; }   // not worth two extra launches
     return p;
 }
 

@@ -46,3 +46,29 @@ def test_ops_refuse_cpu_tensors():
     from regione_amd import ops
     with pytest.raises(_lib.RegionEHipError):
         ops.gather_rows(torch.zeros(1, 4, 64), torch.zeros(1, 2, dtype=torch.int64))
+
+
+def test_argument_validation_returns_codes_and_messages_without_touching_the_gpu():
+    """Every entry point validates before it launches: bad shapes / alignment / null pointers give a negative
+    RGN_E_* code and a message through rgn_last_error() (the Python wrappers turn it into RegionEHipError)."""
+    h = _lib.lib()
+    P = 0x10000                                          # a plausible, 16-byte aligned, never dereferenced address
+
+    def msg():
+        return h.rgn_last_error().decode()
+    # GEMM: K must be a multiple of 64, strides multiples of 8, pointers 16-byte aligned, gate/resid for epilogue 2
+    assert h.rgn_gemm_bf16(P, 96, P, 96, None, P, 64, 8, 64, 96, 0, 0, None, None, None, None, 0, None) < 0 and "multiple of 64" in msg()
+    assert h.rgn_gemm_bf16(P, 68, P, 64, None, P, 64, 8, 64, 64, 0, 0, None, None, None, None, 0, None) < 0 and "strides" in msg()
+    assert h.rgn_gemm_bf16(P + 2, 64, P, 64, None, P, 64, 8, 64, 64, 0, 0, None, None, None, None, 0, None) < 0 and "aligned" in msg()
+    assert h.rgn_gemm_bf16(P, 64, P, 64, None, P, 64, 8, 64, 64, 2, 0, None, None, None, None, 0, None) < 0 and "gate" in msg()
+    assert h.rgn_gemm_bf16(None, 64, P, 64, None, P, 64, 8, 64, 64, 0, 0, None, None, None, None, 0, None) < 0
+    assert h.rgn_gemm_bf16(P, 64, P, 64, None, P, 64, 0, 64, 64, 0, 0, None, None, None, None, 0, None) == 0      # M = 0: nothing to do
+    # fused QKV epilogue: descriptor required, column blocks 256-aligned
+    assert h.rgn_gemm_bf16_qkv(P, 64, P, 64, None, P, 768, 8, 768, 64, 768, None, None, 0, None) < 0 and "rgn_qkv_epilogue" in msg()
+    e = _lib.QkvEpilogue(P, P, P, P, P, P, None, P, P, 0, 64, 0, 128, 512, 2, 1e-6)      # v_col = 128: not 256-aligned
+    assert h.rgn_gemm_bf16_qkv(P, 64, P, 64, None, P, 768, 8, 768, 64, 768, e, None, 0, None) < 0 and "256-aligned" in msg()
+    # attention / row kernels
+    assert h.rgn_attention(None, 0, P, P, 64, P, 0, 8, 8, 2, 0.1, None, 0, None) < 0
+    assert h.rgn_qk_norm_rope_store(P, 12, 0, 0, 0, 8, 2, 0, None, None, P, P, 1e-6, P, P, P, P, None, P, P, 64, None) < 0
+    assert h.rgn_gather_rows(None, P, P, 4, 128, None) < 0
+    assert h.rgn_gemv_bf16(P, 64, P, None, P, 64, 9, 64, 64, 0, None) < 0                 # batch > 4
