@@ -336,27 +336,38 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
             // slab positions 16a + 8p .. +7  ->  one 16-byte store when the kv rows are the identity
             const QkvEpi& q = g.qkv;
             const int rbase = q.row_base + m0 + ch * CROWS;                 // sequence row of chunk row 0
-            const bool ident = (q.kv_rows == nullptr) && ((rbase & 15) == 0);
-            constexpr int ITEMS = BN * (CROWS / 8) / NT;
+            const bool ident = (q.kv_rows == nullptr) && ((rbase & 15) == 0) && (m0 + (ch + 1) * CROWS <= g.M);
+            if (ident) {
+                constexpr int ITEMS = BN * (CROWS / 8) / NT;
 #pragma unroll
-            for (int j = 0; j < ITEMS; ++j) {
-                const int item = tid + j * NT;
-                const int col = item % BN, grp = item / BN;
-                const int a = grp >> 1, ph = grp & 1;
-                const int hd_col = n0 - q.v_col + col;                      // h * 128 + d
-                if (hd_col >= q.hd) continue;
-                uint16_t t[8];
+                for (int j = 0; j < ITEMS; ++j) {
+                    const int item = tid + j * NT;
+                    const int col = item % BN, grp = item / BN;
+                    const int a = grp >> 1, ph = grp & 1;
+                    const int hd_col = n0 - q.v_col + col;                  // h * 128 + d
+                    if (hd_col >= q.hd) continue;
+                    uint16_t t[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t[e] = ct[(16 * a + 4 * ph + (e & 3) + 8 * (e >> 2)) * CT_LD + col];
-                uint16_t* drow = q.vt_slab + (size_t)hd_col * q.skv_pad;
-                const int mlast = m0 + ch * CROWS + 16 * a + 4 * ph + 11;   // largest local row of the item
-                if (ident && mlast < g.M) {
-                    *(uint4*)(drow + rbase + 16 * a + 8 * ph) = *(const uint4*)t;
-                } else {
+                    for (int e = 0; e < 8; ++e) t[e] = ct[(16 * a + 4 * ph + (e & 3) + 8 * (e >> 2)) * CT_LD + col];
+                    *(uint4*)(q.vt_slab + (size_t)hd_col * q.skv_pad + rbase + 16 * a + 8 * ph) = *(const uint4*)t;
+                }
+            } else {
+                // gathered cache rows (region step) or a ragged chunk: lanes run over ROWS, so one store instruction
+                // writes 64 kv positions of one (h, d) row of V^T - contiguous wherever the cache rows are (text rows,
+                // runs of edited tokens) - instead of 64 different rows
+                static_assert(NT % CROWS == 0 || CROWS % NT == 0, "row-major V scatter mapping");
+                constexpr int RPT = (CROWS > NT) ? CROWS / NT : 1;          // rows per thread
+                constexpr int CSTEP = (NT > CROWS) ? NT / CROWS : 1;        // threads sharing a row step through the columns
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int kr = krow[16 * a + 4 * ph + (e & 3) + 8 * (e >> 2)];
-                        if (kr >= 0) drow[kvpos((size_t)kr)] = t[e];
+                for (int rr = 0; rr < RPT; ++rr) {
+                    const int row = (tid % CROWS) + rr * NT;
+                    const int kr = krow[row];
+                    if (kr < 0) continue;
+                    uint16_t* dcol = q.vt_slab + kvpos((size_t)kr);
+                    const uint16_t* src = ct + row * CT_LD;
+                    for (int col = tid / CROWS; col < BN; col += CSTEP) {
+                        const int hd_col = n0 - q.v_col + col;
+                        if (hd_col < q.hd) dcol[(size_t)hd_col * q.skv_pad] = src[col];
                     }
                 }
             }
