@@ -57,7 +57,7 @@ class KernelTimer:
         self.rec = {}
         self.shapes = {}
 
-    def shape_table(self, top=10):
+    def shape_table(self, top=24):
         rows = []
         for (m0, m1, n, k), lst in self.shapes.items():
             ms = sum(s.elapsed_time(e) for s, e in lst)
@@ -304,15 +304,21 @@ def main():
         out = edit()
         D.gather_latents([out], [rank], world, dist)           # warm the collective too (communicator / channel setup)
     timer = KernelTimer()
-    timer.wrap(ops)
 
     def job():
-        for _ in range(args.steps):
+        for k in range(args.steps):
+            # per-launch HIP events cost ~1.3 % of an edit (two marker packets around each of ~900 launches), so only
+            # the LAST timed edit carries them: the roofline figures come from inside the timed region, the headline
+            # number is not paying for its own instrumentation on the other edits
+            instrument = (k == args.steps - 1) and not os.environ.get("RGN_BENCH_NO_KTIMER")
+            if instrument:
+                timer.wrap(ops)
             o = edit()
+            if instrument:
+                timer.unwrap()
             # every rank ends with every image's final latents (512 KB each): the only data collective
             D.gather_latents([o], [rank], world, dist)
     elapsed = D.timed(job, torch.cuda.synchronize, dist)       # barrier + sync both sides, MAX over ranks
-    timer.unwrap()
 
     # characterise the run (untimed): step kinds, K_e
     trace = {}
@@ -352,7 +358,7 @@ def main():
                               "traffic": pmc.get("gemm_bf16_kernel", {}).get("traffic_bytes_per_launch"),
                               "traffic_unit": "bytes/launch (L2->fabric reads x2-corrected + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
                               "launches": k["launches"], "avg_launch_us": k["avg_us"],
-                              "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
+                              "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
     result["gemm_shapes"] = timer.shape_table()
     if "attention_kernel" in ksum:
         k = ksum["attention_kernel"]
@@ -360,7 +366,7 @@ def main():
                                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
                                         "traffic": pmc.get("attention_kernel", {}).get("traffic_bytes_per_launch"),
                                         "launches": k["launches"], "avg_launch_us": k["avg_us"],
-                                        "share_of_edit_time": k["total_ms"] * 1e-3 / elapsed}
+                                        "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
 
     if rank == 0 and world == 1 and not args.no_vanilla:
         # full-token denoising on the same engine: the speed-up the reference headlines (README.md:23)
