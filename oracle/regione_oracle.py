@@ -383,11 +383,14 @@ def flux_pos_embed(ids: torch.Tensor, axes_dim=(16, 56, 56), theta=10000.0):
     return torch.cat(cos_out, -1), torch.cat(sin_out, -1)
 
 
-def timestep_embedding(t: torch.Tensor, dim=256, max_period=10000):
-    """[EXT] get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0)."""
+def timestep_embedding(t: torch.Tensor, dim=256, max_period=10000, scale=1.0):
+    """[EXT] get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0); `scale` multiplies the angles
+    AFTER t * freqs (diffusers `emb = scale * emb`: Qwen's Timesteps(scale=1000) on timestep / 1000)."""
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
     a = t[:, None].float() * freqs[None]
+    if scale != 1.0:
+        a = scale * a
     return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
 
 
@@ -399,12 +402,12 @@ def _mlp_embed(w, name, x):
     return _lin(w, name + ".linear_2", F.silu(_lin(w, name + ".linear_1", x)))
 
 
-def time_text_embed(w, timestep, guidance, pooled):
+def time_text_embed(w, timestep, guidance, pooled, scale=1.0):
     """[EXT] CombinedTimestepGuidanceTextProjEmbeddings."""
     p = "time_text_embed."
     if pooled is None:       # Qwen-Image: conditioning = timestep embedding only [EXT QwenTimestepProjEmbeddings]
         dt = w[p + "timestep_embedder.linear_1.weight"].dtype
-        return _mlp_embed(w, p + "timestep_embedder", timestep_embedding(timestep).to(dt))
+        return _mlp_embed(w, p + "timestep_embedder", timestep_embedding(timestep, scale=scale).to(dt))
     t = _mlp_embed(w, p + "timestep_embedder", timestep_embedding(timestep).to(pooled.dtype))
     if guidance is None:     # Step1X-Edit: temb = time_embed(t) + vec_embed(y)  (Step1XEdit/inplace.py:519-520)
         return t + _mlp_embed(w, p + "text_embedder", pooled)
@@ -530,7 +533,8 @@ def qwen_rope(img_shapes, txt_len, axes_dim=(16, 56, 56), theta=10000.0):
         ang.append(torch.cat([f, hh, ww], -1).reshape(fr * h * w, -1))
         max_vid = max(max_vid, h // 2, w // 2)
     a = torch.cat([torch.cat([p[max_vid: max_vid + txt_len] for p in pos], 1)] + ang, 0)
-    return a.cos().repeat_interleave(2, dim=1), a.sin().repeat_interleave(2, dim=1)
+    z = torch.polar(torch.ones_like(a), a)                 # [EXT] rope_params: torch.polar(ones, freqs), complex64
+    return z.real.repeat_interleave(2, dim=1), z.imag.repeat_interleave(2, dim=1)
 
 
 def transformer_forward(w, cfg: FluxCfg, st: RegionState, caches: List[KVCache], hidden, enc, pooled,
@@ -541,9 +545,14 @@ def transformer_forward(w, cfg: FluxCfg, st: RegionState, caches: List[KVCache],
     if "txt_norm.weight" in w:                       # [EXT] QwenImageTransformer2DModel.txt_norm
         enc = rms_norm(enc, w["txt_norm.weight"])
     h = _lin(w, "x_embedder", hidden)
-    ts = timestep.to(h.dtype) * 1000
-    g = guidance.to(h.dtype) * 1000 if guidance is not None else None
-    temb = time_text_embed(w, ts, g, pooled)
+    if "txt_norm.weight" in w:
+        # Qwen: the forward keeps timestep / 1000 in the model dtype (QwenImageEdit/inplace.py:518) and the [EXT] embedder
+        # scales the ANGLES by 1000 in fp32 - unlike FLUX / Step1X, whose forwards multiply the bf16 timestep by 1000
+        temb = time_text_embed(w, timestep.to(h.dtype), None, None, scale=1000.0)
+    else:
+        ts = timestep.to(h.dtype) * 1000
+        g = guidance.to(h.dtype) * 1000 if guidance is not None else None
+        temb = time_text_embed(w, ts, g, pooled)
     c = _lin(w, "context_embedder", enc)
     if rope_full is not None:
         T = enc.shape[1]

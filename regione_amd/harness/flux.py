@@ -135,11 +135,14 @@ class FluxPosEmbed:
         return self._cache[key]
 
 
-def timestep_embedding(t: torch.Tensor, dim=256, max_period=10000) -> torch.Tensor:
-    """[EXT] get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0); host, fp32."""
+def timestep_embedding(t: torch.Tensor, dim=256, max_period=10000, scale: float = 1.0) -> torch.Tensor:
+    """[EXT] get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0); host, fp32.  `scale` multiplies the
+    angles after t * freqs (diffusers `emb = scale * emb`)."""
     half = dim // 2
     freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
     a = t[:, None].float() * freqs[None]
+    if scale != 1.0:
+        a = scale * a
     return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
 
 
@@ -435,7 +438,7 @@ class FluxTransformer2DModel:
             h = ops.gemv(x, getattr(self, f"tte_{e}_linear_1_weight"), getattr(self, f"tte_{e}_linear_1_bias"))
             return ops.gemv(h, getattr(self, f"tte_{e}_linear_2_weight"), getattr(self, f"tte_{e}_linear_2_bias"),
                             silu_input=True)
-        te = timestep_embedding(timestep.detach().float().cpu()).to(torch.bfloat16).to(self.device)
+        te = timestep_embedding(timestep.detach().float().cpu(), scale=self.ts_angle_scale).to(torch.bfloat16).to(self.device)
         t = mlp("timestep_embedder", te)
         if not self.cfg_model.pooled_embeds or pooled is None:
             return t              # Qwen-Image: conditioning = timestep embedding only
@@ -456,7 +459,7 @@ class FluxTransformer2DModel:
         gd = guidance.to(torch.bfloat16) * 1000 if guidance is not None else None
         keys, rows = [], []
         for ts in timesteps_div1000:
-            tsb = ts.to(torch.bfloat16) * 1000
+            tsb = self._ts_key(ts)
             k = float(tsb[0])
             if k in keys:
                 continue
@@ -472,6 +475,16 @@ class FluxTransformer2DModel:
 
     def clear_modulations(self):
         self._mod_tables = {}
+
+    @property
+    def ts_angle_scale(self) -> float:
+        """Qwen's [EXT] embedder is Timesteps(scale=1000) applied to timestep / 1000 (angles scaled in fp32); FLUX and
+        Step1X multiply the bf16 timestep by 1000 in the forward (inplace.py:471, Step1XEdit/inplace.py:519)."""
+        return 1000.0 if self.cfg_model.txt_norm else 1.0
+
+    def _ts_key(self, timestep_div1000: torch.Tensor) -> torch.Tensor:
+        t = timestep_div1000.to(torch.bfloat16)
+        return t if self.cfg_model.txt_norm else t * 1000
 
     def _lookup_modulation(self, ts, gd, pooled) -> Optional[Modulation]:
         mt = getattr(self, "_mod_tables", {}).get(0 if pooled is None else pooled.data_ptr())
@@ -504,7 +517,7 @@ class FluxTransformer2DModel:
         if self.cfg_model.txt_norm:
             enc = ops.rms_norm_rows(enc, self.txt_norm_weight)
         ops.gemm(enc, self.context_embedder_weight, self.context_embedder_bias, ws.x[:T])
-        ts = timestep.to(torch.bfloat16) * 1000                       # inplace.py:471
+        ts = self._ts_key(timestep)                                   # inplace.py:471
         gd = guidance.to(torch.bfloat16) * 1000 if guidance is not None else None
         mods = self._lookup_modulation(ts, gd, pooled)
         if mods is None:

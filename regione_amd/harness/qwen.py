@@ -55,8 +55,11 @@ class QwenEmbedRope:
             max_vid = max(max_vid, h // 2, w // 2) if self.scale_rope else max(max_vid, h, w)
         txt = torch.cat([p[max_vid: max_vid + txt_len] for p in self.pos], dim=1)
         a = torch.cat([txt] + ang, dim=0)                                  # [T + N, 64] angles
-        cos = a.cos().repeat_interleave(2, dim=1).contiguous().to(device)
-        sin = a.sin().repeat_interleave(2, dim=1).contiguous().to(device)
+        # diffusers builds the table as torch.polar(1, angle) (complex64); its real / imaginary parts differ from
+        # angle.cos() / angle.sin() by an ulp here and there, and parity is against THAT table
+        z = torch.polar(torch.ones_like(a), a)
+        cos = z.real.repeat_interleave(2, dim=1).contiguous().to(device)
+        sin = z.imag.repeat_interleave(2, dim=1).contiguous().to(device)
         return cos, sin
 
 

@@ -693,6 +693,106 @@ def gen_toy_cfg(ns):
     print("   lens:", rec["len"][:8], " K_e =", rec["edited_ids"].shape[1], "kinds", "".join(rec["kinds"]))
 
 
+def gen_qwen_toy(ns):
+    """Reference RegionEQwenImageEditPipeline.__call__ + RegionEQwenImageTransformer2DModelforward + the reference's
+    two-cache tagged attention processor (QwenImageEdit/inplace.py:462-571, 725-890) around [EXT] Qwen block stubs,
+    toy dims, true CFG 4.0 with different cond / uncond text lengths."""
+    import diffusers
+    ip = ns.qwen
+    dtype = torch.bfloat16
+    cfg = synth.FluxConfig(**synth.QWEN_TOY)
+    h = w = 16
+    L, T, Tn = h * w, 32, 24
+    wts = synth.make_flux_weights(cfg, seed=6, dtype=dtype, w_std=0.05)
+    model = ref_stubs.QwenImageTransformer2DModel(in_channels=cfg.in_channels, n_double=cfg.n_double, heads=cfg.heads,
+                                                  head_dim=cfg.head_dim, joint_dim=cfg.joint_dim, axes_dim=cfg.axes_dim).to(dtype)
+    rename = {"x_embedder.": "img_in.", "context_embedder.": "txt_in."}
+    sd = {}
+    for k, v in wts.items():
+        for a, b in rename.items():
+            if k.startswith(a):
+                k = b + k[len(a):]
+        sd[k] = v.clone()
+    missing = [k for k in model.state_dict() if k not in sd]
+    assert not missing, missing[:5]
+    model.load_state_dict({k: sd[k] for k in model.state_dict()})
+    model.eval()
+    latents, image_latents, prompt, _ = synth.make_edit_inputs(h, w, T, cfg, seed=9, dtype=dtype)
+    _, _, nprompt, _ = synth.make_edit_inputs(h, w, Tn, cfg, seed=10, dtype=dtype)
+
+    def run(cond_latents):
+        pipe = diffusers.QwenImageEditPipeline()
+        pipe.scheduler = ref_stubs.FlowMatchEulerDiscreteScheduler()
+        pipe.transformer = model
+        pipe.image_processor = ref_stubs._Cfg(resize=lambda im, hh, ww: im,
+                                              preprocess=lambda im, hh, ww: torch.zeros(1, 3, hh, ww))
+        pipe.encode_prompt = lambda **k: ((nprompt, torch.ones(1, Tn)) if k.get("prompt") == " " else (prompt, torch.ones(1, T)))
+        pipe.prepare_latents = lambda *a, **k: (latents.clone(), cond_latents.clone())
+        rcfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.5,
+                    cache_threshold=0.03, erosion_dilation=True)
+        ip.warp_modules(pipe, **rcfg)
+        # the reference resizes every input image to ~1024^2 (calculate_dimensions); the toy condition latents are
+        # h x w tokens, so the size helper is pinned to the toy size for this run (img_shapes must match the latents)
+        orig_calc = ip.calculate_dimensions
+        ip.calculate_dimensions = lambda area, ratio: (w * 16, h * 16, None)
+        rec = {k: [] for k in ("noise_pred", "len", "latents", "calls")}
+        sch = pipe.scheduler
+        orig_step, orig_mstep = sch.step, ip.MANAGER.step
+
+        def step_hook(model_output, timestep, sample, **kw):
+            rec["noise_pred"].append(model_output.clone())
+            return orig_step(model_output, timestep, sample, **kw)
+
+        def mstep_hook(latent, latent_ids):
+            out = orig_mstep(latent, latent_ids)
+            rec["len"].append(out[0].shape[1])
+            rec["latents"].append(out[0].clone())
+            return out
+        handle = model.register_forward_pre_hook(
+            lambda mod, a, kw: rec["calls"].append((ip.MANAGER.current_step, kw["hidden_states"].shape[1])), with_kwargs=True)
+        sch.step, ip.MANAGER.step = step_hook, mstep_hook
+        img = ref_stubs._Cfg(size=(w * 16, h * 16))
+        try:
+            with torch.no_grad():
+                out = pipe(image=img, prompt="edit", negative_prompt=" ", height=h * 16, width=w * 16,
+                           num_inference_steps=28, true_cfg_scale=4.0, output_type="latent", return_dict=False)
+        finally:
+            ip.MANAGER.step = orig_mstep
+            ip.calculate_dimensions = orig_calc
+            handle.remove()
+        rec["final"], rec["sigmas"] = out[0], sch.sigmas
+        rec["edited_ids"] = ip.MANAGER.edited_ids
+        # the reference's processors keep their caches: one (K, V) pair per CFG branch
+        p0 = model.transformer_blocks[0].attn.processor
+        rec["k_even"], rec["v_odd"] = p0.k_cache_even, p0.v_cache_odd
+        called = dict(rec["calls"])
+        rec["kinds"] = ["C" if i not in called else ("F" if called[i] == 2 * L else "R") for i in range(28)]
+        return rec
+    # pass 1 with an arbitrary condition -> craft a condition that gives a non-trivial region (see gen_kv_and_toy)
+    rec = run(image_latents)
+    x5 = rec["latents"][4]
+    est = x5.float() + (rec["sigmas"][-1] - rec["sigmas"][5]) * rec["noise_pred"][5].float()
+    box = torch.zeros(h, w, dtype=torch.bool)
+    box[4:12, 3:11] = True
+    g = torch.Generator().manual_seed(3)
+    cond = est + 0.35 * torch.randn(est.shape, generator=g) * est.std()
+    cond[0, box.reshape(-1)] = torch.randn(int(box.sum()), 64, generator=g)
+    image_latents2 = cond.to(dtype)
+    rec = run(image_latents2)
+    d = dict(h=h, w=w, T=T, Tn=Tn, seed=9, nseed=10, wseed=6, w_std=0.05, threshold=0.5, cache_threshold=0.03, true_cfg_scale=4.0,
+             image_latents=image_latents2, len=np.array(rec["len"]), final=rec["final"], kinds=np.array(rec["kinds"]),
+             edited_ids=rec["edited_ids"].to(torch.int32),
+             weight_abs_sum=float(sum(v.double().abs().sum() for v in wts.values())),
+             np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+             lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]),
+             kcache_even_b0=rec["k_even"], vcache_odd_b0=rec["v_odd"])
+    for i in (0, 5, 6, 15, 27):
+        d[f"np{i}"] = rec["noise_pred"][i]
+        d[f"lat{i}"] = rec["latents"][i]
+    save("qwen_toy_bf16", d)
+    print("   kinds:", "".join(rec["kinds"]), " K_e =", rec["edited_ids"].shape[1], "/", L)
+
+
 def load_npz(name):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_golden
@@ -721,6 +821,8 @@ def main():
         gen_qwen_loop(ns)
     if "v1p2" in which or not sys.argv[1:]:
         gen_step1x_v1p2_loop(ns)
+    if "qwentoy" in which or not sys.argv[1:]:
+        gen_qwen_toy(ns)
 
 
 if __name__ == "__main__":

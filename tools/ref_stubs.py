@@ -256,13 +256,15 @@ class FluxSingleTransformerBlock(nn.Module):
         return hidden_states[:, :text_seq_len], hidden_states[:, text_seq_len:]
 
 
-def get_timestep_embedding(timesteps, embedding_dim=256, max_period=10000):
-    """[EXT] flip_sin_to_cos=True, downscale_freq_shift=0, scale=1."""
+def get_timestep_embedding(timesteps, embedding_dim=256, max_period=10000, scale=1.0):
+    """[EXT] flip_sin_to_cos=True, downscale_freq_shift=0; `scale` multiplies the ANGLES (diffusers: emb = scale * emb)."""
     half = embedding_dim // 2
     exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
     exponent = exponent / half
     emb = torch.exp(exponent)
     emb = timesteps[:, None].float() * emb[None, :]
+    if scale != 1.0:
+        emb = scale * emb
     emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
     return torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
 
@@ -314,6 +316,98 @@ class FluxTransformer2DModel(nn.Module):
             [FluxSingleTransformerBlock(d, heads, head_dim) for _ in range(n_single)])
         self.norm_out = AdaLayerNormContinuous(d, d)
         self.proj_out = nn.Linear(d, in_channels, bias=True)
+
+    def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
+        raise RuntimeError("vanilla forward not restated; reference rebinding expected")
+
+
+# ----- Qwen-Image [EXT] stubs (diffusers transformer_qwenimage.py semantics, restated) -----------------
+class QwenImageTransformerBlock(FluxTransformerBlock):
+    """[EXT] QwenImageTransformerBlock: img_mod / txt_mod = SiLU + Linear(d, 6d) chunked (shift1, scale1, gate1,
+    shift2, scale2, gate2), LayerNorm(no affine, eps 1e-6), joint attention, FeedForward(gelu-approximate) -
+    the same dataflow and parameter shapes as the FLUX double block, so the FLUX stub is reused under the FLUX
+    parameter names (norm1 = img_mod, norm1_context = txt_mod, ff = img_mlp, ff_context = txt_mlp)."""
+
+    def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, temb=None,
+                image_rotary_emb=None, joint_attention_kwargs=None):
+        kw = joint_attention_kwargs or {}
+        norm_h, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, emb=temb)
+        norm_c, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(encoder_hidden_states, emb=temb)
+        attn_output, context_attn_output = self.attn(
+            hidden_states=norm_h, encoder_hidden_states=norm_c, encoder_hidden_states_mask=encoder_hidden_states_mask,
+            image_rotary_emb=image_rotary_emb, **kw)
+        hidden_states = hidden_states + gate_msa.unsqueeze(1) * attn_output
+        encoder_hidden_states = encoder_hidden_states + c_gate_msa.unsqueeze(1) * context_attn_output
+        norm_h = self.norm2(hidden_states) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+        hidden_states = hidden_states + gate_mlp.unsqueeze(1) * self.ff(norm_h)
+        norm_c = self.norm2_context(encoder_hidden_states) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+        encoder_hidden_states = encoder_hidden_states + c_gate_mlp.unsqueeze(1) * self.ff_context(norm_c)
+        return encoder_hidden_states, hidden_states
+
+
+class QwenTimestepProjEmbeddings(nn.Module):
+    """[EXT] Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0, scale=1000) + TimestepEmbedding."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.timestep_embedder = _MLPEmbed(256, d)
+
+    def forward(self, timestep, hidden_states):
+        proj = get_timestep_embedding(timestep, 256, scale=1000.0)       # Timesteps(..., scale=1000) on timestep / 1000
+        return self.timestep_embedder(proj.to(hidden_states.dtype))
+
+
+class QwenEmbedRope(nn.Module):
+    """[EXT] QwenEmbedRope(theta, axes_dim, scale_rope=True): complex tables (vid_freqs [sum f*h*w, 64], txt_freqs [T, 64])."""
+
+    def __init__(self, theta=10000, axes_dim=(16, 56, 56)):
+        super().__init__()
+        self.theta, self.axes_dim = theta, axes_dim
+        pos_index, neg_index = torch.arange(4096), torch.arange(4096).flip(0) * -1 - 1
+        self.pos_freqs = torch.cat([self._params(pos_index, d) for d in axes_dim], dim=1)
+        self.neg_freqs = torch.cat([self._params(neg_index, d) for d in axes_dim], dim=1)
+
+    def _params(self, index, dim):
+        freqs = torch.outer(index.float(), 1.0 / torch.pow(self.theta, torch.arange(0, dim, 2).to(torch.float32).div(dim)))
+        return torch.polar(torch.ones_like(freqs), freqs)
+
+    def forward(self, video_fhw, txt_seq_lens, device=None):
+        if isinstance(video_fhw, list) and isinstance(video_fhw[0], (list, tuple)) and isinstance(video_fhw[0][0], (list, tuple)):
+            video_fhw = video_fhw[0]
+        vid, max_vid = [], 0
+        half = [x // 2 for x in self.axes_dim]
+        for idx, (frame, height, width) in enumerate(video_fhw):
+            fp = self.pos_freqs.split(half, dim=1)
+            fn = self.neg_freqs.split(half, dim=1)
+            f = fp[0][idx: idx + frame].view(frame, 1, 1, -1).expand(frame, height, width, -1)
+            hh = torch.cat([fn[1][-(height - height // 2):], fp[1][: height // 2]], 0).view(1, height, 1, -1).expand(frame, height, width, -1)
+            ww = torch.cat([fn[2][-(width - width // 2):], fp[2][: width // 2]], 0).view(1, 1, width, -1).expand(frame, height, width, -1)
+            vid.append(torch.cat([f, hh, ww], dim=-1).reshape(frame * height * width, -1))
+            max_vid = max(max_vid, height // 2, width // 2)
+        max_len = int(max(txt_seq_lens))
+        return torch.cat(vid, 0), self.pos_freqs[max_vid: max_vid + max_len]
+
+
+class QwenImageTransformer2DModel(nn.Module):
+    """[EXT] module tree of diffusers QwenImageTransformer2DModel; forward is replaced by the reference."""
+
+    def __init__(self, in_channels=64, n_double=3, heads=2, head_dim=128, joint_dim=256, axes_dim=(16, 56, 56)):
+        super().__init__()
+        d = heads * head_dim
+        self.config = _Cfg(in_channels=in_channels, guidance_embeds=False)
+        self.gradient_checkpointing = False
+        self.pos_embed = QwenEmbedRope(theta=10000, axes_dim=axes_dim)
+        self.time_text_embed = QwenTimestepProjEmbeddings(d)
+        self.txt_norm = RMSNorm(joint_dim, eps=1e-6)
+        self.img_in = nn.Linear(in_channels, d)
+        self.txt_in = nn.Linear(joint_dim, d)
+        self.transformer_blocks = nn.ModuleList([QwenImageTransformerBlock(d, heads, head_dim) for _ in range(n_double)])
+        self.norm_out = AdaLayerNormContinuous(d, d)
+        self.proj_out = nn.Linear(d, in_channels, bias=True)
+
+    def cache_context(self, name):
+        from contextlib import nullcontext
+        return nullcontext()
 
     def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
         raise RuntimeError("vanilla forward not restated; reference rebinding expected")
