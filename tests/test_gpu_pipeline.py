@@ -405,3 +405,34 @@ def test_qwen_toy_mmdit_vs_reference_fixture(golden):
         assert O.psnr(trace["noise_pred"][i].cpu(), g[f"np{i}"]) > 35.0, i
         assert O.psnr(trace["latents"][i].cpu(), g[f"lat{i}"]) > 40.0, i
     assert O.psnr(out, g["final"]) >= 40.0
+
+
+@pytest.mark.parametrize("name,v1p2", [("s1x_toy_bf16", False), ("s1xv2_toy_bf16", True)])
+def test_step1x_toy_mmdit_vs_reference_fixture(golden, name, v1p2):
+    """Step1X-Edit v1p1 (batched CFG) / v1p2 (tagged sequential CFG, text lengths 32 / 24) patch sets on the HIP engine
+    against fixtures produced by the REFERENCE's own __call__ + transformer forward + attention processors: plan and
+    edited ids exact, velocities / latents / final output within the north-star tolerance."""
+    from regione_amd.harness import step1x as HS
+    g = golden(name)
+    h, w, T, Tn = g["h"], g["w"], g["T"], g["Tn"]
+    cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=g["wseed"], dtype=torch.bfloat16, w_std=g["w_std"])
+    assert float(sum(v.double().abs().sum() for v in wts.values())) == g["weight_abs_sum"], "torch RNG drift"
+    lat, _, prompt, y = synth.make_edit_inputs(h, w, T, cfg, seed=g["seed"], dtype=torch.bfloat16)
+    _, _, nprompt, ny = synth.make_edit_inputs(h, w, Tn, cfg, seed=g["nseed"], dtype=torch.bfloat16)
+    img = g["image_latents"]
+    tr_model = HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts)
+    pipe = HS.Step1XEditPipelineV1P2(tr_model) if v1p2 else HS.Step1XEditPipeline(tr_model)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=g["threshold"], cache_threshold=g["cache_threshold"])
+    helper.enable()
+    trace = {}
+    out = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=y.cuda(), negative_prompt_embeds=nprompt.cuda(),
+               negative_pooled_prompt_embeds=ny.cuda(), height=h * 16, width=w * 16, latents=lat.cuda(),
+               true_cfg_scale=g["true_cfg_scale"], return_dict=False, trace=trace)[0].cpu()
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    assert torch.equal(pipe._regione_manager.edited_ids.cpu().squeeze(0).int(), g["edited_ids"].squeeze(0))
+    for i in (0, 5, 6, 15, 27):
+        assert O.psnr(trace["noise_pred"][i].cpu(), g[f"np{i}"]) > 35.0, i
+        assert O.psnr(trace["latents"][i].cpu(), g[f"lat{i}"]) > 40.0, i
+    assert O.psnr(out, g["final"]) >= 40.0

@@ -693,6 +693,121 @@ def gen_toy_cfg(ns):
     print("   lens:", rec["len"][:8], " K_e =", rec["edited_ids"].shape[1], "kinds", "".join(rec["kinds"]))
 
 
+def gen_step1x_toy(ns, v1p2: bool):
+    """Reference Step1X-Edit __call__ + transformer forward + attention processors around [EXT] FLUX-shaped block stubs
+    at toy dims.  v1p1 (Step1XEdit/inplace.py): batched true CFG (B = 2 rows through ONE cache per processor);
+    v1p2 (Step1XEditV1P2/inplace.py): sequential tagged CFG, one cache per tag, different cond / uncond text lengths."""
+    import diffusers
+    ip = ns.step1x_v1p2 if v1p2 else ns.step1x
+    dtype = torch.bfloat16
+    cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
+    h = w = 16
+    L, T = h * w, 32
+    Tn = 24 if v1p2 else 32
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=dtype, w_std=0.05)
+    model = ref_stubs.Step1XEditTransformer2DModel(in_channels=cfg.in_channels, n_double=cfg.n_double, n_single=cfg.n_single,
+                                                   heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim,
+                                                   pooled_dim=cfg.pooled_dim, axes_dim=cfg.axes_dim).to(dtype)
+    rename = {"time_text_embed.timestep_embedder.": "time_embed.", "time_text_embed.text_embedder.": "vec_embed."}
+    sd = {}
+    for k, v in wts.items():
+        for a, b in rename.items():
+            if k.startswith(a):
+                k = b + k[len(a):]
+        sd[k] = v.clone()
+    missing = [k for k in model.state_dict() if k not in sd]
+    assert not missing, missing[:5]
+    model.load_state_dict({k: sd[k] for k in model.state_dict()})
+    model.eval()
+    latents, image_latents, prompt, y = synth.make_edit_inputs(h, w, T, cfg, seed=9, dtype=dtype)
+    _, _, nprompt, ny = synth.make_edit_inputs(h, w, Tn, cfg, seed=10, dtype=dtype)
+    model.set_vec(prompt, y)
+    model.set_vec(nprompt, ny)
+    ids_full = synth.flux_latent_ids(h, w)
+
+    def run(cond_latents):
+        pipe = diffusers.Step1XEditPipelineV1P2() if v1p2 else diffusers.Step1XEditPipeline()
+        pipe.scheduler = ref_stubs.FlowMatchEulerDiscreteScheduler()
+        pipe.transformer = model
+        pipe.prepare_latents = lambda *a, **k: (latents.clone(), cond_latents.clone(), ids_full[:L].clone(), ids_full[L:].clone())
+        if v1p2:
+            pe = ref_stubs._Cfg(embedding=prompt, mask=None, txt_ids=torch.zeros(T, 3), text_embeds=None, text_masks=None)
+            ne = ref_stubs._Cfg(embedding=nprompt, mask=None, txt_ids=torch.zeros(Tn, 3), text_embeds=None, text_masks=None)
+            pipe.encode_image = lambda image, width, height, size_level, device, n: (image, None, None, width, height)
+            pipe.encode_prompt = lambda **k: (ne if k.get("prompt") == "" else pe)
+        else:
+            pipe.encode_image = lambda image, width, height, device, n: (image, None, None, width, height)
+            pipe.encode_prompt = lambda **k: (k["prompt_embeds"], k["prompt_embeds_mask"], torch.zeros(k["prompt_embeds"].shape[1], 3))
+        rcfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=0.5,
+                    cache_threshold=0.02, erosion_dilation=True)
+        ip.warp_modules(pipe, **rcfg)
+        rec = {k: [] for k in ("noise_pred", "len", "latents", "calls")}
+        sch = pipe.scheduler
+        orig_step, orig_mstep = sch.step, ip.MANAGER.step
+
+        def step_hook(model_output, timestep, sample, **kw):
+            rec["noise_pred"].append(model_output.clone())
+            return orig_step(model_output, timestep, sample, **kw)
+
+        def mstep_hook(latent, latent_ids):
+            out = orig_mstep(latent, latent_ids)
+            rec["len"].append(out[0].shape[1])
+            rec["latents"].append(out[0].clone())
+            return out
+        handle = model.register_forward_pre_hook(
+            lambda mod, a, kw: rec["calls"].append((ip.MANAGER.current_step, kw["hidden_states"].shape[1])), with_kwargs=True)
+        sch.step, ip.MANAGER.step = step_hook, mstep_hook
+        try:
+            with torch.no_grad():
+                if v1p2:
+                    try:
+                        out = pipe(image=torch.zeros(1, 3, 8, 8), prompt="edit", negative_prompt="", height=h * 16, width=w * 16,
+                                   num_inference_steps=28, true_cfg_scale=4.0, output_type="latent", return_dict=False,
+                                   enable_thinking_mode=False, enable_reflection_mode=False)
+                    except RuntimeError as e:           # the v1p2 post-loop `if out_images` on a latent tensor (SURVEY quirk)
+                        print("   (post-loop:", str(e)[:60], ")")
+                        out = None
+                else:
+                    out = pipe(image=torch.zeros(1, 3, 8, 8), prompt_embeds=prompt, prompt_embeds_mask=torch.ones(1, T),
+                               negative_prompt_embeds=nprompt, negative_prompt_embeds_mask=torch.ones(1, Tn), height=h * 16,
+                               width=w * 16, num_inference_steps=28, true_cfg_scale=4.0, guidance_scale=6.0,
+                               output_type="latent", return_dict=False)
+        finally:
+            ip.MANAGER.step = orig_mstep
+            handle.remove()
+        rec["final"] = rec["latents"][-1]
+        rec["sigmas"] = sch.sigmas
+        rec["edited_ids"] = ip.MANAGER.edited_ids
+        called = dict(rec["calls"])
+        rec["kinds"] = ["C" if i not in called else ("F" if called[i] == 2 * L else "R") for i in range(28)]
+        p0 = model.transformer_blocks[0].attn.processor
+        ps = model.single_transformer_blocks[0].attn.processor
+        rec["caches"] = (dict(k_d0_even=p0.k_cache_even, v_s0_odd=ps.v_cache_odd) if v1p2 else dict(k_d0=p0.k_cache, v_s0=ps.v_cache))
+        return rec
+    rec = run(image_latents)
+    x5 = rec["latents"][4]
+    est = x5.float() + (rec["sigmas"][-1] - rec["sigmas"][5]) * rec["noise_pred"][5].float()
+    box = torch.zeros(h, w, dtype=torch.bool)
+    box[4:12, 3:11] = True
+    g = torch.Generator().manual_seed(3)
+    cond = est + 0.35 * torch.randn(est.shape, generator=g) * est.std()
+    cond[0, box.reshape(-1)] = torch.randn(int(box.sum()), 64, generator=g)
+    image_latents2 = cond.to(dtype)
+    rec = run(image_latents2)
+    d = dict(h=h, w=w, T=T, Tn=Tn, seed=9, nseed=10, wseed=5, w_std=0.05, threshold=0.5, cache_threshold=0.02, true_cfg_scale=4.0,
+             image_latents=image_latents2, len=np.array(rec["len"]), final=rec["final"], kinds=np.array(rec["kinds"]),
+             edited_ids=rec["edited_ids"].to(torch.int32),
+             weight_abs_sum=float(sum(v.double().abs().sum() for v in wts.values())),
+             np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+             lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]), **rec["caches"])
+    for i in (0, 5, 6, 15, 27):
+        d[f"np{i}"] = rec["noise_pred"][i]
+        d[f"lat{i}"] = rec["latents"][i]
+    name = "s1xv2_toy_bf16" if v1p2 else "s1x_toy_bf16"
+    save(name, d)
+    print("   kinds:", "".join(rec["kinds"]), " K_e =", rec["edited_ids"].shape[1], "/", L)
+
+
 def gen_qwen_toy(ns):
     """Reference RegionEQwenImageEditPipeline.__call__ + RegionEQwenImageTransformer2DModelforward + the reference's
     two-cache tagged attention processor (QwenImageEdit/inplace.py:462-571, 725-890) around [EXT] Qwen block stubs,
@@ -823,6 +938,10 @@ def main():
         gen_step1x_v1p2_loop(ns)
     if "qwentoy" in which or not sys.argv[1:]:
         gen_qwen_toy(ns)
+    if "s1xtoy" in which or not sys.argv[1:]:
+        gen_step1x_toy(ns, v1p2=False)
+    if "v1p2toy" in which or not sys.argv[1:]:
+        gen_step1x_toy(ns, v1p2=True)
 
 
 if __name__ == "__main__":

@@ -215,7 +215,8 @@ class FluxTransformerBlock(nn.Module):
         norm_h, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, emb=temb)
         norm_c, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(encoder_hidden_states, emb=temb)
         attn_output, context_attn_output = self.attn(
-            hidden_states=norm_h, encoder_hidden_states=norm_c, image_rotary_emb=image_rotary_emb)
+            hidden_states=norm_h, encoder_hidden_states=norm_c, image_rotary_emb=image_rotary_emb,
+            **(joint_attention_kwargs or {}))
         attn_output = gate_msa.unsqueeze(1) * attn_output
         hidden_states = hidden_states + attn_output
         norm_h = self.norm2(hidden_states)
@@ -249,7 +250,7 @@ class FluxSingleTransformerBlock(nn.Module):
         residual = hidden_states
         norm_h, gate = self.norm(hidden_states, emb=temb)
         mlp_h = F.gelu(self.proj_mlp(norm_h), approximate="tanh")
-        attn_output = self.attn(hidden_states=norm_h, image_rotary_emb=image_rotary_emb)
+        attn_output = self.attn(hidden_states=norm_h, image_rotary_emb=image_rotary_emb, **(joint_attention_kwargs or {}))
         hidden_states = torch.cat([attn_output, mlp_h], dim=2)
         hidden_states = gate.unsqueeze(1) * self.proj_out(hidden_states)
         hidden_states = residual + hidden_states
@@ -316,6 +317,49 @@ class FluxTransformer2DModel(nn.Module):
             [FluxSingleTransformerBlock(d, heads, head_dim) for _ in range(n_single)])
         self.norm_out = AdaLayerNormContinuous(d, d)
         self.proj_out = nn.Linear(d, in_channels, bias=True)
+
+    def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
+        raise RuntimeError("vanilla forward not restated; reference rebinding expected")
+
+
+# ----- Step1X-Edit [EXT] stubs (FLUX trunk; diffusers-fork transformer_step1x_edit.py semantics, restated) -----
+class Step1XEditTransformer2DModel(nn.Module):
+    """[EXT] module tree the reference's Step1X forwards touch (Step1XEdit/inplace.py:514-522,
+    Step1XEditV1P2/inplace.py:602-621): connector -> (encoder states, pooled y), x_embedder, time_proj / time_embed,
+    vec_embed, context_embedder, pos_embed, FLUX-shaped double / single blocks, norm_out, proj_out.  The real
+    connector is a Qwen2-VL adapter; here it hands through the prompt embeddings and returns the pooled vector that
+    was registered for that prompt (`set_vec`), which is what the engine takes as an input too."""
+
+    def __init__(self, in_channels=64, n_double=2, n_single=2, heads=2, head_dim=128, joint_dim=256,
+                 pooled_dim=64, axes_dim=(16, 56, 56)):
+        super().__init__()
+        d = heads * head_dim
+        self.config = _Cfg(in_channels=in_channels, guidance_embeds=False)
+        self.gradient_checkpointing = False
+        self.text_token_mapping = None
+        self.pos_embed = FluxPosEmbed(theta=10000, axes_dim=axes_dim)
+        self.time_embed = _MLPEmbed(256, d)
+        self.vec_embed = _MLPEmbed(pooled_dim, d)
+        self.context_embedder = nn.Linear(joint_dim, d)
+        self.x_embedder = nn.Linear(in_channels, d)
+        self.transformer_blocks = nn.ModuleList([FluxTransformerBlock(d, heads, head_dim) for _ in range(n_double)])
+        self.single_transformer_blocks = nn.ModuleList(
+            [FluxSingleTransformerBlock(d, heads, head_dim) for _ in range(n_single)])
+        for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+            b.attn.added_kv_proj_dim = d if hasattr(b.attn, "add_q_proj") else None
+        self.norm_out = AdaLayerNormContinuous(d, d)
+        self.proj_out = nn.Linear(d, in_channels, bias=True)
+        self._vec = {}
+
+    def set_vec(self, prompt_embeds, y):
+        self._vec[float(prompt_embeds.float().sum())] = y
+
+    def time_proj(self, timestep):
+        return get_timestep_embedding(timestep, 256)
+
+    def connector(self, encoder_hidden_states, timestep, mask):
+        ys = [self._vec[float(encoder_hidden_states[b:b + 1].float().sum())] for b in range(encoder_hidden_states.shape[0])]
+        return encoder_hidden_states, torch.cat(ys, 0)
 
     def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
         raise RuntimeError("vanilla forward not restated; reference rebinding expected")
