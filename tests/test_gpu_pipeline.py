@@ -436,3 +436,34 @@ def test_step1x_toy_mmdit_vs_reference_fixture(golden, name, v1p2):
         assert O.psnr(trace["noise_pred"][i].cpu(), g[f"np{i}"]) > 35.0, i
         assert O.psnr(trace["latents"][i].cpu(), g[f"lat{i}"]) > 40.0, i
     assert O.psnr(out, g["final"]) >= 40.0
+
+
+def test_pipeline_reuse_no_state_leak_between_edits():
+    """One engine, many edits: different images / region sizes / latent grids, RegionE toggled off and on in between.
+    Re-running the first edit at the end must reproduce its first result BIT FOR BIT (no stale K/V cache rows, ids,
+    modulation tables or workspace contents survive from the edits in between)."""
+    cfg = synth.FluxConfig(**synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+    pipe = _toy_pipe({k: v.cuda() for k, v in wts.items()}, cfg)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.3)
+
+    def edit(h, w, seed, T=32):
+        lat, img, prompt, pooled = [t.cuda() for t in synth.make_edit_inputs(h, w, T, cfg, seed=seed, dtype=torch.bfloat16)]
+        out = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=h * 16, width=w * 16, latents=lat,
+                   guidance_scale=2.5, return_dict=False)[0]
+        M = getattr(pipe, "_regione_manager", None)
+        return out.clone(), (None if M is None or M.edited_ids is None else M.edited_ids.clone())
+    helper.enable()
+    first, ids_first = edit(16, 16, 1)
+    edit(16, 16, 2)                       # another image, another region
+    edit(24, 16, 3, T=40)                 # another latent grid and text length (workspace / cache slabs grow)
+    helper.disable()
+    van1, _ = edit(16, 16, 1)             # full-token run of image 1
+    helper.enable()
+    edit(12, 12, 4)                       # smaller again
+    again, ids_again = edit(16, 16, 1)
+    assert torch.equal(ids_first, ids_again) and torch.equal(first, again)
+    helper.disable()
+    van2, _ = edit(16, 16, 1)
+    assert torch.equal(van1, van2) and torch.isfinite(first.float()).all()
