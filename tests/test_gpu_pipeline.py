@@ -472,8 +472,8 @@ def test_pipeline_reuse_no_state_leak_between_edits():
 @pytest.mark.parametrize("h,w,T", [(13, 11, 19), (7, 30, 5), (33, 17, 77)])
 def test_ragged_sizes_forward_and_regione_run(h, w, T):
     """Token counts that are multiples of nothing (GEMM / attention / cache-scatter tails): one full forward vs the
-    oracle, then a whole RegionE edit vs the oracle loop (same plan, >= 40 dB; ids compared when the partition is not
-    numerically marginal)."""
+    oracle (>= 40 dB), then a whole RegionE edit with a constructed region: finite, the reference-logic step plan, the
+    compacted length inside the region-aware stage."""
     cfg = synth.FluxConfig(**synth.TOY)
     wts = synth.make_flux_weights(cfg, seed=11, dtype=torch.bfloat16, w_std=0.05)
     lat, img, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=21, dtype=torch.bfloat16)
