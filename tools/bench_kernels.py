@@ -89,6 +89,38 @@ def bench_small():
             print(f"pair[{variant:>4}] {name:<18} M={M0}+{M1:<4} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  (ideal@1150 {fl/1150e6:6.1f} us)")
 
 
+def bench_region():
+    """The region-partition ops (O(L * 64) bytes -> launch-latency bound; achieved GB/s reported for
+    honesty) next to the oracle's CPU time for the same call."""
+    import time
+    from oracle import regione_oracle as O
+    for L, h, w in ((4096, 64, 64), (16384, 128, 128)):
+        g = torch.Generator().manual_seed(0)
+        sample = torch.randn(1, L, 64, generator=g)
+        cond = torch.randn(1, L, 64, generator=g).to(torch.bfloat16)
+        v = ((cond.float() - sample) / -0.7 + (torch.rand(1, L, 1, generator=g) > 0.7) * torch.randn(1, L, 64, generator=g)).to(torch.bfloat16)
+        sc, cc, vc = sample.cuda(), cond.cuda(), v.cuda()
+        e, u, mask, raw, _ = ops.arp_partition(sc, vc, cc, -0.7, 0.88, h, w, True)
+        K = e.numel()
+        cases = [
+            ("arp_partition", lambda: ops.arp_partition(sc, vc, cc, -0.7, 0.88, h, w, True), L * 64 * (4 + 2 + 2) + L + 8 * L,
+             lambda: O.token_selector(sample + torch.tensor(-0.7) * v, cond, 0.88, h, w, True)),
+            ("gather_rows", lambda: ops.gather_rows(cc, e), 2 * K * 64 * 2, lambda: O.ids_gather(cond, e.cpu())),
+            ("scatter_rows_", lambda: ops.scatter_rows_(ops.gather_rows(cc, e), e, cc), 2 * K * 64 * 2, None),
+            ("euler_step (split)", lambda: ops.euler_step(sc, vc, -0.03, mask, -0.5), L * 64 * (4 + 2) + L * 64 * 2, None),
+            ("avd_apply (gather)", lambda: ops.avd_apply(vc, 1.0173, e), 2 * K * 64 * 2, lambda: O.ids_gather(v, e.cpu()) * torch.tensor(1.0173)),
+        ]
+        for name, fn, nbytes, cpu in cases:
+            med, best = timeit(fn, iters=5, warm=2, inner=50)
+            line = f"region L={L:<6} K_e={K:<6} {name:<20} {med*1e3:7.1f} us  {nbytes/med/1e6:7.1f} GB/s"
+            if cpu is not None:
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    cpu()
+                line += f"   | oracle on CPU {(time.perf_counter()-t0)/5*1e6:9.1f} us ({torch.get_num_threads()} threads)"
+            print(line)
+
+
 def bench_attn():
     for name, Sq, Skv, H in [("full", 8704, 8704, 24), ("region 25%", 1536, 8704, 24), ("region 5%", 717, 8704, 24)]:
         D = H * 128
@@ -114,5 +146,6 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "gemv"]
     if "gemm" in which: bench_gemm()
     if "small" in which: bench_small()
+    if "region" in which: bench_region()
     if "attn" in which: bench_attn()
     if "gemv" in which: bench_gemv()
