@@ -155,6 +155,8 @@ typedef struct rgn_qkv_epilogue {
     void* vt_slab;             /* [heads*128][skv_pad] bf16 */
     int row_base, skv_pad, k_col, v_col, q_col, heads;
     float eps;
+    int fp16_roundtrip;        /* 1: K / V columns round fp32 -> fp16 -> bf16 like the reference's partial-update kernel
+                                  (fused_kernels.py:80); 0: one rounding, like F.linear on store / plain steps */
 } rgn_qkv_epilogue;
 #define RGN_EPI_QKV 3
 int rgn_gemm_bf16_qkv(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,

@@ -27,7 +27,7 @@ class QkvEpilogue(C.Structure):
     _fields_ = [("wq", _c_void_p), ("wk", _c_void_p), ("cos_q", _c_void_p), ("sin_q", _c_void_p), ("cos_k", _c_void_p),
                 ("sin_k", _c_void_p), ("kv_rows", _c_void_p), ("k_slab", _c_void_p), ("vt_slab", _c_void_p),
                 ("row_base", _c_int), ("skv_pad", _c_int), ("k_col", _c_int), ("v_col", _c_int), ("q_col", _c_int),
-                ("heads", _c_int), ("eps", _c_float)]
+                ("heads", _c_int), ("eps", _c_float), ("fp16_roundtrip", _c_int)]
 
 
 _qkv_p = C.POINTER(QkvEpilogue)

@@ -40,6 +40,7 @@ struct QkvEpi {
     uint16_t* vt_slab;           // [heads * 128][skv_pad], kv index permuted inside 16-groups
     int row_base;                // sequence row of this problem's row 0
     int skv_pad, k_col, v_col, q_col, hd;     // hd = heads * 128
+    int fp16_roundtrip;          // K / V columns round fp32 -> fp16 -> bf16 (the reference's partial-update kernel)
     float eps;
 };
 
@@ -314,10 +315,20 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                         for (int r = 0; r < 4; ++r) if (n0 + nl + r < g.N) bv[r] = bf2f(g.bias[n0 + nl + r]);
                     }
                 }
+                // the reference's partial K/V update (_triton_matmul_index_kernel) stores `accumulator.to(tl.float16)` into
+                // the bf16 cache (fused_kernels.py:80, quirk A-3): K / V columns of a partial-update problem take the same
+                // fp32 -> fp16 -> bf16 double rounding; every other column rounds once, like F.linear
+                const bool f16rt = (EPI == RGN_EPI_QKV) && g.qkv.fp16_roundtrip && n0 < g.qkv.q_col;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const uint2 w = make_uint2(cvt_pk_bf16(acc[i][j][0] + bv[0], acc[i][j][1] + bv[1]),
-                                               cvt_pk_bf16(acc[i][j][2] + bv[2], acc[i][j][3] + bv[3]));
+                    float c[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = acc[i][j][r] + bv[r];
+                    if (f16rt) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c[r] = (float)(_Float16)c[r];
+                    }
+                    const uint2 w = make_uint2(cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3]));
                     *(uint2*)(ct + (crow0 + i * 16 + mrow) * CT_LD + nl) = w;
                 }
             }
@@ -682,7 +693,7 @@ static int fill_qkv(GemmArgs& g, const rgn_qkv_epilogue* e, int N) {
     q.cos_q = e->cos_q; q.sin_q = e->sin_q; q.cos_k = e->cos_k; q.sin_k = e->sin_k;
     q.kv_rows = e->kv_rows; q.k_slab = (uint16_t*)e->k_slab; q.vt_slab = (uint16_t*)e->vt_slab;
     q.row_base = e->row_base; q.skv_pad = e->skv_pad; q.k_col = e->k_col; q.v_col = e->v_col; q.q_col = e->q_col;
-    q.hd = hd; q.eps = e->eps;
+    q.hd = hd; q.eps = e->eps; q.fp16_roundtrip = e->fp16_roundtrip;
     return 0;
 }
 

@@ -233,13 +233,16 @@ class FluxAttnProcessor:
         k_slab, vt_slab, kv_rows, skv, rope_k = self.kv_target(attn, ctx)
         rope_k = rope_k if rope_k is not None else image_rotary_emb
         fuse = FUSE_QKV and H % 2 == 0             # the fused epilogue works on 256-column (two-head) blocks
+        # partial K/V update (region step): the rows the reference sends through `_partially_linear` round fp32 -> fp16 ->
+        # bf16 (fused_kernels.py:80, quirk A-3): every row of a single-stream block, the image rows of a double-stream one
+        partial = kv_rows is not None
         if fuse:
             epi = dict(rope_q=image_rotary_emb, rope_k=rope_k, k_slab=k_slab, vt_slab=vt_slab, H=H, k_col=0, v_col=d,
                        q_col=2 * d, kv_rows=kv_rows)
         if not self.single:
             if fuse:       # projections + RMSNorm + RoPE + K / V^T cache placement of both streams: ONE launch
                 ops.gemm_qkv_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
-                                  ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, row_base=T, **epi),
+                                  ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, row_base=T, fp16_roundtrip=partial, **epi),
                                   ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d],
                                   ops.qkv_epilogue(wq=attn.norm_added_q, wk=attn.norm_added_k, row_base=0, **epi))
             else:
@@ -255,7 +258,8 @@ class FluxAttnProcessor:
             return ws.x[T:R], ws.x[:T]
         # single stream: one GEMM produces [k | v | q | gelu(mlp)] from the same normed activations
         if fuse:
-            ops.gemm_qkv(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, **epi),
+            ops.gemm_qkv(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide,
+                         ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, fp16_roundtrip=partial, **epi),
                          gelu_from_col=3 * d)
         else:
             ops.gemm(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * d)

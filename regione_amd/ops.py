@@ -195,14 +195,14 @@ def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, g
 
 
 def qkv_epilogue(*, wq, wk, rope_q, rope_k, k_slab, vt_slab, H: int, k_col: int, v_col: int, q_col: int,
-                 kv_rows: Optional[torch.Tensor] = None, row_base: int = 0, eps: float = 1e-6):
+                 kv_rows: Optional[torch.Tensor] = None, row_base: int = 0, eps: float = 1e-6, fp16_roundtrip: bool = False):
     """Descriptor of the fused Q/K/V epilogue (struct rgn_qkv_epilogue); keeps its tensors alive."""
     skv_pad = k_slab.shape[0]
     assert vt_slab.shape == (H * 128, skv_pad) and k_slab.shape[1] == H * 128 and k_slab.is_contiguous() and vt_slab.is_contiguous()
     for t in (rope_q[0], rope_q[1], rope_k[0], rope_k[1]):
         assert t.dtype == torch.float32 and t.shape[1] == 128 and t.is_contiguous()
     e = _lib.QkvEpilogue(_p(wq), _p(wk), _p(rope_q[0]), _p(rope_q[1]), _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows),
-                         _p(k_slab), _p(vt_slab), row_base, skv_pad, k_col, v_col, q_col, H, eps)
+                         _p(k_slab), _p(vt_slab), row_base, skv_pad, k_col, v_col, q_col, H, eps, int(fp16_roundtrip))
     e._keep = (wq, wk, rope_q, rope_k, kv_rows, k_slab, vt_slab)
     return e
 

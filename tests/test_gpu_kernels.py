@@ -369,3 +369,27 @@ def test_gemm_qkv_pair_and_full_size_split_path():
     ops.gemm_qkv(A, W, b, out, ops.qkv_epilogue(wq=wq, wk=wk, rope_q=rope, rope_k=rope, k_slab=k1, vt_slab=v1, H=H, k_col=0,
                                                 v_col=D, q_col=2 * D), gelu_from_col=3 * D)
     assert torch.equal(out[:, 2 * D:], wide[:, 2 * D:]) and torch.equal(k1, k0) and torch.equal(v1, v0)
+
+
+def test_gemm_qkv_fp16_roundtrip_option():
+    """rgn_qkv_epilogue.fp16_roundtrip = 1 (the reference's partial-update kernel stores acc.to(fp16) into the bf16 cache,
+    fused_kernels.py:80): only the K / V columns change, by at most one bf16 ulp; Q and the MLP half are untouched."""
+    from regione_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    M, H, K, mlp = 300, 2, 256, 512
+    A, W, b, wq, wk, rope, D, N, skv = _qkv_case(M, H, K, mlp, gen)
+    skv_pad = ops.padded(skv)
+    res = []
+    for rt in (False, True):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        ks = torch.zeros(skv_pad, D, dtype=torch.bfloat16, device="cuda")
+        vs = torch.zeros(D, skv_pad, dtype=torch.bfloat16, device="cuda")
+        epi = ops.qkv_epilogue(wq=wq, wk=wk, rope_q=rope, rope_k=rope, k_slab=ks, vt_slab=vs, H=H, k_col=0, v_col=D, q_col=2 * D,
+                               fp16_roundtrip=rt)
+        ops.gemm_qkv(A, W, b, out, epi, gelu_from_col=3 * D)
+        res.append((out, ks, vs))
+    (o0, k0, v0), (o1, k1, v1) = res
+    assert torch.equal(o0, o1)                                               # Q, GELU(mlp): single rounding either way
+    dv = (v0.float() - v1.float()).abs()
+    assert float((v0 != v1).float().mean()) > 0.0 and float((dv / v0.float().abs().clamp_min(1e-3)).max()) <= 2 ** -7
+    assert float((k0.float() - k1.float()).abs().max()) <= 2 ** -5 * float(k0.float().abs().max())
