@@ -509,3 +509,25 @@ def test_ragged_sizes_forward_and_regione_run(h, w, T):
     assert kinds == "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04)).replace("S", "F")
     K = pipe._regione_manager.edited_ids.numel()
     assert 0 < K < L and [x_.shape[1] for x_ in trace["latents"]][6] == K
+
+
+@pytest.mark.parametrize("threshold,expect", [(-2.0, "none"), (2.0, "all")])
+def test_degenerate_partitions_nothing_or_everything_edited(threshold, expect):
+    """K_e = 0 (no token below the threshold) and K_e = L (every token) must run: region steps
+    then work on the text rows only / on all noise tokens against the cached condition tokens."""
+    cfg = synth.FluxConfig(**synth.TOY)
+    h = w = 16
+    T, L = 32, 256
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+    pipe = _toy_pipe({k: v.cuda() for k, v in wts.items()}, cfg)
+    lat, img, prompt, pooled = [t.cuda() for t in synth.make_edit_inputs(h, w, T, cfg, seed=3, dtype=torch.bfloat16)]
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=threshold)
+    helper.enable()
+    trace = {}
+    out = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=h * 16, width=w * 16, latents=lat,
+               guidance_scale=2.5, return_dict=False, trace=trace)[0]
+    K = pipe._regione_manager.edited_ids.numel()
+    assert K == (0 if expect == "none" else L)
+    assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
+    assert "".join(trace["kind"]) == "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04)).replace("S", "F")
