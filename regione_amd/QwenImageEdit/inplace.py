@@ -13,6 +13,7 @@ from typing import Optional
 
 import torch
 
+from .. import dist as D
 from .. import ops
 from ..FluxKontext import inplace as fk
 from ..harness import flux as H
@@ -94,14 +95,16 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
                 if MANAGER.is_full_input_step():                                         # :364-365
                     x = torch.cat([latents, image_latents], dim=1)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
-                noise_pred = tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=prompt_embeds,
-                                img_shapes=img_shapes, latent_ids=latent_ids, attention_kwargs={"tag": "cond"},
-                                return_dict=False)[0][:, : latents.size(1)]              # :371-384
-                if do_true_cfg:                                                          # :386-405
-                    neg = tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=negative_prompt_embeds,
-                             img_shapes=img_shapes, latent_ids=latent_ids, attention_kwargs={"tag": "uncond"},
-                             return_dict=False)[0][:, : latents.size(1)]
+                def branch(embeds, tag):
+                    return tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=embeds, img_shapes=img_shapes,
+                              latent_ids=latent_ids, attention_kwargs={"tag": tag}, return_dict=False)[0][:, : latents.size(1)]
+                if do_true_cfg:                                                          # :371-405
+                    noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
+                                                         lambda: branch(prompt_embeds, "cond"),
+                                                         lambda: branch(negative_prompt_embeds, "uncond"))
                     noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
+                else:
+                    noise_pred = branch(prompt_embeds, "cond")
                 cache = noise_pred
             if trace is not None:
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))

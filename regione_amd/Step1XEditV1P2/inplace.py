@@ -17,6 +17,7 @@ from typing import Optional
 
 import torch
 
+from .. import dist as D
 from .. import ops
 from ..FluxKontext import inplace as fk
 from ..harness import flux as H
@@ -97,13 +98,13 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
                 if MANAGER.is_full_input_step():
                     x = torch.cat([latents, image_latents], dim=1)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
-                pos = tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=prompt_embeds,
-                         prompt_embeds_mask=None, txt_ids=text_ids, img_ids=latent_ids,
-                         joint_attention_kwargs={"tag": "cond"}, return_dict=False)[0][:, : latents.size(1)]      # :388-401
-                neg = tr(hidden_states=x, timestep=timestep / 1000, guidance=None,
-                         encoder_hidden_states=negative_prompt_embeds, prompt_embeds_mask=None, txt_ids=neg_text_ids,
-                         img_ids=latent_ids, joint_attention_kwargs={"tag": "uncond"},
-                         return_dict=False)[0][:, : latents.size(1)]                                                 # :403-419
+                def branch(embeds, ids, tag):                                                                       # :388-419
+                    return tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=embeds,
+                              prompt_embeds_mask=None, txt_ids=ids, img_ids=latent_ids, joint_attention_kwargs={"tag": tag},
+                              return_dict=False)[0][:, : latents.size(1)]
+                pos, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
+                                              lambda: branch(prompt_embeds, text_ids, "cond"),
+                                              lambda: branch(negative_prompt_embeds, neg_text_ids, "uncond"))
                 mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN                    # :421
                 noise_pred = ops.cfg_combine(pos, neg, true_cfg_scale, mode, process_norm_power)
                 cache = noise_pred

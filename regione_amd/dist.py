@@ -4,6 +4,14 @@ The hot path shards per image: every image owns its edited-token set, K/V cache 
 cache, so ranks never exchange anything during denoising.  One process per GPU (RCCL = backend
 "nccl" on ROCm; "gloo" in the CPU tests), weights replicated.  The only collectives are the barrier
 around the timed region, a MAX-reduce of the elapsed time and an all_gather of the final latents.
+
+Optional second axis: CFG-branch sharding for the families whose reference
+patch sets run the two CFG branches as two separate forwards with separate K/V caches (Qwen-Image-Edit,
+Step1X-Edit v1p2: `k_cache_even/odd`).  Two ranks own ONE image; rank 2p runs the 'cond' forward, rank
+2p+1 the 'uncond' forward, and per computed step they exchange `noise_pred` ([1, K_e or L, 64] bf16,
+<= 512 KB: one 2-rank all_gather, latency-bound on a single xGMI link).  Everything after the exchange
+(CFG combine, scheduler step, region partition, decay-cache decisions) is replicated and deterministic,
+so both ranks hold bit-identical latents / ids and no further traffic is needed.
 """
 from __future__ import annotations
 
@@ -80,3 +88,50 @@ def timed(fn: Callable[[], None], sync: Callable[[], None], dist=None) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     return el
+
+
+class CfgBranchPair:
+    """One rank's view of a CFG pair: `role` is the branch this rank computes; `exchange(mine)` returns
+    (cond, uncond) on both ranks."""
+
+    ROLES = ("cond", "uncond")
+
+    def __init__(self, dist, group, index_in_pair: int):
+        self.dist, self.group, self.index = dist, group, int(index_in_pair)
+
+    @property
+    def role(self) -> str:
+        return self.ROLES[self.index]
+
+    def exchange(self, mine: torch.Tensor):
+        dev = mine.device
+        host = self.dist.get_backend(self.group) == "gloo" and mine.is_cuda     # debugging path (ranks sharing one GPU)
+        send = mine.contiguous().cpu() if host else mine.contiguous()
+        both = [torch.empty_like(send), torch.empty_like(send)]
+        self.dist.all_gather(both, send, group=self.group)
+        if host:
+            both = [b.to(dev) for b in both]
+        both[self.index] = mine           # keep the local tensor (no copy; identical bytes)
+        return both[0], both[1]
+
+
+def make_cfg_pair(dist) -> CfgBranchPair:
+    """Ranks (2p, 2p+1) form pair p.  Collective over the WORLD (every rank must create every group)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world % 2:
+        raise ValueError(f"CFG-branch sharding needs an even number of ranks, got {world}")
+    mine = None
+    for p in range(world // 2):
+        g = dist.new_group(ranks=[2 * p, 2 * p + 1])
+        if rank // 2 == p:
+            mine = g
+    return CfgBranchPair(dist, mine, rank % 2)
+
+
+def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch.Tensor], run_uncond: Callable[[], torch.Tensor]):
+    """Both CFG forwards of one computed step: sequentially (reference order: cond, then uncond) without a pair,
+    one branch per rank + exchange with one."""
+    if pair is None:
+        pos = run_cond()
+        return pos, run_uncond()
+    return pair.exchange(run_cond() if pair.role == "cond" else run_uncond())

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import dist as D
 from .. import ops
 from ..synth import FluxConfig
 from . import flux as H
@@ -127,14 +128,16 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
         for i, t in enumerate(timesteps):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
-            noise_pred = tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=prompt_embeds,
-                            img_shapes=img_shapes, latent_ids=latent_ids, attention_kwargs={"tag": "cond"},
-                            return_dict=False)[0][:, : latents.size(1)]
+            def branch(embeds, tag):
+                return tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=embeds, img_shapes=img_shapes,
+                          latent_ids=latent_ids, attention_kwargs={"tag": tag}, return_dict=False)[0][:, : latents.size(1)]
             if do_true_cfg:
-                neg = tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=negative_prompt_embeds,
-                         img_shapes=img_shapes, latent_ids=latent_ids, attention_kwargs={"tag": "uncond"},
-                         return_dict=False)[0][:, : latents.size(1)]
+                noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
+                                                     lambda: branch(prompt_embeds, "cond"),
+                                                     lambda: branch(negative_prompt_embeds, "uncond"))
                 noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
+            else:
+                noise_pred = branch(prompt_embeds, "cond")
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
         if not return_dict:
             return (latents,)

@@ -15,6 +15,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .. import dist as D
 from .. import ops
 from ..synth import FluxConfig
 from . import flux as H
@@ -118,11 +119,12 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
         for i, t in enumerate(timesteps):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
-            outs = []
-            for pe, y, ids_t, tag in ((prompt_embeds, pooled_prompt_embeds, text_ids, "cond"),
-                                      (negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond")):
+            def branch(pe, y, ids_t, tag):
                 rope = tr.pos_embed(torch.cat((ids_t, latent_ids), dim=0), tr.device)
-                outs.append(tr._run(x, pe, y, timestep / 1000, None, rope, False, {"tag": tag})[0][:, : latents.size(1)])
+                return tr._run(x, pe, y, timestep / 1000, None, rope, False, {"tag": tag})[0][:, : latents.size(1)]
+            outs = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
+                                      lambda: branch(prompt_embeds, pooled_prompt_embeds, text_ids, "cond"),
+                                      lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond"))
             mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN
             noise_pred = ops.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]

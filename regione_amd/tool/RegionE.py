@@ -64,6 +64,16 @@ class RegionEHelper(object):
         assert self.pipeline is not None
         self.pipeline = self._family().unwarp_modules(self.pipeline)
 
+    def shard_cfg_branches(self, pair):
+        """Extension: run the 'cond' and 'uncond' forwards of one image on the two ranks of
+        `pair` (regione_amd.dist.make_cfg_pair) and exchange noise_pred per computed step.  Only for the families whose
+        reference patch sets keep one K/V cache per branch; `pair=None` switches it off.  Works enabled or disabled
+        (the full-token loop shards the same way)."""
+        if pair is not None and _FAMILY[self.name] not in ("QwenImageEdit", "QwenImageEditPlus", "Step1XEditV1P2"):
+            raise NotImplementedError(f"{self.name} does not run CFG as two independent forwards (FLUX is guidance-distilled, "
+                                      "Step1X-Edit v1p1 batches the branches): shard by image instead")
+        self.pipeline._cfg_pair = pair
+
     def set_params(self, num_inference_steps=28, warmup_step=None, post_step=None, refresh_step=None, threshold=None,
                    cache_threshold=None, erosion_dilation=None, strict_reference=None, gamma=None):
         # reference: 28 steps only (tool/RegionE.py:44).  Extension: `gamma` = N-1 fitted decay factors (list / tensor,

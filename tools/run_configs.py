@@ -29,7 +29,6 @@ import torch  # noqa: E402
 
 import bench as B  # noqa: E402
 from regione_amd import RegionEHelper, synth  # noqa: E402
-from oracle import regione_oracle as O  # noqa: E402  (checker only: derive_schedule / psnr)
 
 
 def weights_stream(cfg, device, seed):
@@ -63,6 +62,7 @@ def make_box(h_tok, w_tok, frac):
 def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, timed_edits=1, vanilla_runs=2, steps=28,
              helper_kw=None):
     from regione_amd.harness import flux as HF, step1x as HS, qwen as HQ
+    from oracle import regione_oracle as O      # checker only: derive_schedule / psnr
     h_tok = w_tok = size // 16
     L = h_tok * w_tok
     if family == "flux":
