@@ -44,7 +44,8 @@ def resample_gamma(table, num_inference_steps: int):
 class RegionEHelper(object):
     def __init__(self, pipeline=None):
         if pipeline is not None:
-            self.pipeline = pipeline
+            # a hosted pipeline (regione_amd.adapters.adopt) keeps the host for pre / post; the patch set goes on its engine
+            self.pipeline = getattr(pipeline, "_regione_engine", pipeline)
         self.name = self.pipeline.__class__.__name__
         # per-helper copy: the reference mutates the module-level dict in set_params (RegionE.py:43-51),
         # which leaks settings between helpers; same defaults, no leak.
