@@ -37,6 +37,8 @@ def bench_gemm():
               ("double txt qkv", 512, 9216, 3072), ("double txt ff2", 512, 3072, 12288),
               ("region kvq+mlp", 1536, 21504, 3072), ("region proj_out", 1536, 3072, 15360),
               ("region img out", 1024, 3072, 3072), ("square 8192", 8192, 8192, 8192)]
+    if os.environ.get("GEMM_KSWEEP"):      # 1024 tiles = 4 exact rounds: per-tile time = a*K + b separates loop rate from tile overhead
+        shapes = [(f"ksweep {k}", 8192, 8192, k) for k in (512, 1024, 2048, 3072, 4096, 8192)]
     only = os.environ.get("GEMM_ONLY")
     for name, M, N, K in shapes:
         if only and only not in name:
