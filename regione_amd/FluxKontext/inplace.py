@@ -140,6 +140,7 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                 if MANAGER.is_full_input_step():                                # inplace.py:331-332
                     latent_model_input = torch.cat([latents, image_latents], dim=1)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
+                self.transformer.out_rows_hint = latents.size(1)
                 noise_pred = self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000,
                                               guidance=guidance, pooled_projections=pooled_prompt_embeds,
                                               encoder_hidden_states=prompt_embeds, txt_ids=text_ids,
@@ -147,6 +148,7 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                                               return_dict=False)[0]
                 noise_pred = noise_pred[:, : latents.size(1)]
                 if do_true_cfg:                                                 # inplace.py:349-364
+                    self.transformer.out_rows_hint = latents.size(1)
                     neg = self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000,
                                            guidance=guidance, pooled_projections=negative_pooled_prompt_embeds,
                                            encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,

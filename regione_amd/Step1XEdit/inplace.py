@@ -99,6 +99,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
                 assert do_true_cfg, "the reference leaves noise_pred undefined without true CFG (:381-399)"
                 xb, pe = self._batched_inputs(x, prompt_embeds, negative_prompt_embeds)
                 timestep = torch.cat((timestep, timestep), dim=0)
+                tr.out_rows_hint = latents.size(1)
                 noise_pred = tr(hidden_states=xb, timestep=timestep / 1000, guidance=None, encoder_hidden_states=pe,
                                 prompt_embeds_mask=None, txt_ids=text_ids, img_ids=latent_ids, return_dict=False)[0]
                 noise_pred = noise_pred[:, : latents.size(1)]

@@ -99,6 +99,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
                     x = torch.cat([latents, image_latents], dim=1)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
                 def branch(embeds, ids, tag):                                                                       # :388-419
+                    tr.out_rows_hint = latents.size(1)
                     return tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=embeds,
                               prompt_embeds_mask=None, txt_ids=ids, img_ids=latent_ids, joint_attention_kwargs={"tag": tag},
                               return_dict=False)[0][:, : latents.size(1)]

@@ -186,8 +186,11 @@ class Modulation:
 class FwdCtx:
     """Per-forward context handed to the processors alongside the reference's arguments."""
 
-    def __init__(self, ws: Workspace, T: int, M: int, mods: Modulation, tag=None):
+    def __init__(self, ws: Workspace, T: int, M: int, mods: Modulation, tag=None, out_rows=None):
         self.ws, self.T, self.M, self.mods, self.tag = ws, T, M, mods, tag
+        # the caller only reads the first `out_rows` image rows of the forward's output (pipelines slice
+        # `[:, :latents.size(1)]`, inplace.py:346): the LAST block may skip every row nothing downstream reads
+        self.out_rows = out_rows
 
 
 # ---------------------------------------------------------------------------------------------
@@ -196,6 +199,8 @@ class FwdCtx:
 # RGN_FUSE_QKV=0 keeps RMSNorm / RoPE / cache placement as the separate rgn_qk_norm_rope_store pass (A/B switch;
 # both paths produce bit-identical results, tests/test_gpu_kernels.py)
 FUSE_QKV = os.environ.get("RGN_FUSE_QKV", "1") != "0"
+# RGN_SKIP_UNREAD_ROWS=0: the last block and norm_out / proj_out run over every row like the reference (A/B switch)
+SKIP_UNREAD_ROWS = os.environ.get("RGN_SKIP_UNREAD_ROWS", "1") != "0"
 
 
 class Attention:
@@ -257,6 +262,20 @@ class FluxAttnProcessor:
                           epilogue=ops.EPI_GATE_RESID, gate0=g_img, resid0=ws.x[T:R], gate1=g_txt, resid1=ws.x[:T])
             return ws.x[T:R], ws.x[:T]
         # single stream: one GEMM produces [k | v | q | gelu(mlp)] from the same normed activations
+        n_out = ctx.out_rows if (block is not None and getattr(block, "is_last", False)) else None
+        if n_out is not None and n_out < M and not partial:
+            # last block of a full step: keys / values of every row, but queries, MLP, attention and (in the block)
+            # proj_out only for the rows the caller reads - the text and condition-image rows of this block's output feed
+            # nothing.  (Region steps keep the one-launch path: their K/V rows carry the fp16 round trip of quirk A-3.)
+            lo, hi = T, T + n_out
+            ops.gemm(ws.nrm[:R], attn.w_kvqm[:2 * d], attn.b_kvqm[:2 * d], wide[:, :2 * d])
+            ops.gemm(ws.nrm[lo:hi], attn.w_kvqm[2 * d:], attn.b_kvqm[2 * d:], wide[lo:hi, 2 * d:], epilogue=ops.EPI_GELU,
+                     gelu_from_col=d)
+            ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
+                                   vt_slab, kv_rows)
+            q = wide[lo:hi, 2 * d:3 * d]
+            ops.attention(q, k_slab, vt_slab, q, skv, H)
+            return wide[lo:hi, 2 * d:]
         if fuse:
             ops.gemm_qkv(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide,
                          ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, fp16_roundtrip=partial, **epi),
@@ -319,8 +338,8 @@ class FluxSingleTransformerBlock:
         R = T + M
         ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo, 0), mods.chunk(self.mo, 1))
         cat = self.attn(hidden_states=ws.nrm[:R], image_rotary_emb=image_rotary_emb, ctx=ctx, block=self)
-        ops.gemm(cat, self.w_po, self.b_po, ws.x[:R], epilogue=ops.EPI_GATE_RESID, gate=mods.chunk(self.mo, 2),
-                 resid=ws.x[:R])
+        rows = ws.x[:R] if cat.shape[0] == R else ws.x[T:T + cat.shape[0]]      # last block: only the rows the caller reads
+        ops.gemm(cat, self.w_po, self.b_po, rows, epilogue=ops.EPI_GATE_RESID, gate=mods.chunk(self.mo, 2), resid=rows)
         return ws.x[:T], ws.x[T:R]
 
 
@@ -344,6 +363,8 @@ class FluxTransformer2DModel:
         for _ in range(cfg.n_single):
             self.single_transformer_blocks.append(FluxSingleTransformerBlock(cfg, off))
             off += 3 * d
+        if self.single_transformer_blocks:
+            self.single_transformer_blocks[-1].is_last = True       # its output feeds only norm_out / proj_out
         self.mo_out = off
         self.mod_total = off + 2 * d
         self.ws = Workspace(cfg, self.device)
@@ -508,10 +529,17 @@ class FluxTransformer2DModel:
         return self.forward(*a, **k)
 
     def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict,
-             joint_attention_kwargs=None):
-        """Shared body of the vanilla and the RegionE forward (inplace.py:469-576)."""
+             joint_attention_kwargs=None, out_rows=None):
+        """Shared body of the vanilla and the RegionE forward (inplace.py:469-576).  `out_rows` (or the one-shot attribute
+        `out_rows_hint` a pipeline sets right before the call): only the first `out_rows` image rows of the result are
+        read by the caller -> the result has that many rows and the last block skips the others."""
         assert hidden_states.shape[0] == 1, "harness engine runs one image per forward"
+        if out_rows is None:
+            out_rows = self.__dict__.pop("out_rows_hint", None)
+        if not SKIP_UNREAD_ROWS:
+            out_rows = None
         M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
+        Mo = M if out_rows is None else min(int(out_rows), M)
         R = T + M
         ws = self.ws
         ws.ensure(R, R)
@@ -527,15 +555,16 @@ class FluxTransformer2DModel:
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
-        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"))
+        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo)
         for block in self.transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
         for block in self.single_transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
         # norm_out (AdaLayerNormContinuous: scale, shift = chunk(emb, 2)) + proj_out
-        ops.ln_modulate(ws.x[T:R], ws.nrm[T:R], mods.chunk(self.mo_out, 1), mods.chunk(self.mo_out, 0))
-        out = torch.empty(1, M, self.cfg_model.in_channels, dtype=torch.bfloat16, device=self.device)
-        ops.gemm(ws.nrm[T:R], self.proj_out_weight, self.proj_out_bias, out[0])
+        Ro = T + Mo
+        ops.ln_modulate(ws.x[T:Ro], ws.nrm[T:Ro], mods.chunk(self.mo_out, 1), mods.chunk(self.mo_out, 0))
+        out = torch.empty(1, Mo, self.cfg_model.in_channels, dtype=torch.bfloat16, device=self.device)
+        ops.gemm(ws.nrm[T:Ro], self.proj_out_weight, self.proj_out_bias, out[0])
         return (out,) if not return_dict else _Cfg(sample=out)
 
 
@@ -613,12 +642,14 @@ class FluxKontextPipeline:
         for i, t in enumerate(timesteps):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
+            self.transformer.out_rows_hint = latents.size(1)
             noise_pred = self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance,
                                           pooled_projections=pooled_prompt_embeds,
                                           encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_ids,
                                           return_dict=False)[0]
             noise_pred = noise_pred[:, : latents.size(1)]
             if do_true_cfg:
+                self.transformer.out_rows_hint = latents.size(1)
                 neg = self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance,
                                        pooled_projections=negative_pooled_prompt_embeds,
                                        encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,

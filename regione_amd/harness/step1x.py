@@ -48,10 +48,11 @@ class Step1XEditTransformer2DModel(H.FluxTransformer2DModel):
                      return_dict):
         enc, y = self.connector(encoder_hidden_states, timestep, prompt_embeds_mask)
         outs = []
+        out_rows = self.__dict__.pop("out_rows_hint", None)
         for b in range(hidden_states.shape[0]):
             tag = "cond" if b == 0 else "uncond"
             outs.append(self._run(hidden_states[b:b + 1], enc[b:b + 1], y[b], timestep[b:b + 1], None, image_rotary_emb,
-                                  False, {"tag": tag})[0])
+                                  False, {"tag": tag}, out_rows=out_rows)[0])
         out = torch.cat(outs, 0)
         return (out,) if not return_dict else H._Cfg(sample=out)
 
@@ -91,6 +92,7 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
             x, pe = self._batched_inputs(torch.cat([latents, image_latents], dim=1), prompt_embeds, negative_prompt_embeds)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             timestep = torch.cat((timestep, timestep), dim=0)
+            tr.out_rows_hint = latents.size(1)
             noise_pred = tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=pe,
                             prompt_embeds_mask=None, txt_ids=text_ids, img_ids=latent_ids, return_dict=False)[0]
             noise_pred = noise_pred[:, : latents.size(1)]
@@ -121,7 +123,8 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             def branch(pe, y, ids_t, tag):
                 rope = tr.pos_embed(torch.cat((ids_t, latent_ids), dim=0), tr.device)
-                return tr._run(x, pe, y, timestep / 1000, None, rope, False, {"tag": tag})[0][:, : latents.size(1)]
+                return tr._run(x, pe, y, timestep / 1000, None, rope, False, {"tag": tag},
+                               out_rows=latents.size(1))[0][:, : latents.size(1)]
             outs = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                       lambda: branch(prompt_embeds, pooled_prompt_embeds, text_ids, "cond"),
                                       lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond"))

@@ -531,3 +531,58 @@ def test_degenerate_partitions_nothing_or_everything_edited(threshold, expect):
     assert K == (0 if expect == "none" else L)
     assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
     assert "".join(trace["kind"]) == "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04)).replace("S", "F")
+
+
+@pytest.mark.parametrize("family", ["flux", "step1x_v1p2"])
+def test_last_block_skips_rows_nothing_reads_same_result(family, monkeypatch):
+    """harness/flux.py `out_rows`: the pipelines read only `[:, :latents.size(1)]` of a forward, so in a full step the last
+    single block computes queries / MLP / attention / proj_out (and norm_out / proj_out) for the latent rows only.  Same
+    latents and ids as with every row computed like the reference does (RGN_SKIP_UNREAD_ROWS=0), RegionE on and off; a direct
+    transformer call without the hint still returns every row."""
+    from regione_amd.harness import step1x as HS
+    h = w = 16
+    if family == "flux":
+        cfg = synth.FluxConfig(**synth.TOY)
+        wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+        pipe = _toy_pipe({k: v.cuda() for k, v in wts.items()}, cfg)
+    else:
+        cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
+        wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+        pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+    lat, img, prompt, y = [t.cuda() for t in synth.make_edit_inputs(h, w, 32, cfg, seed=9, dtype=torch.bfloat16)]
+    _, _, nprompt, ny = [t.cuda() if t is not None else None for t in synth.make_edit_inputs(h, w, 24, cfg, seed=10, dtype=torch.bfloat16)]
+    blk = torch.zeros(h, w, dtype=torch.bool)
+    blk[4:10, 5:12] = True                                   # a region by construction: condition == start latents outside it
+    img = lat.clone()
+    img[0, blk.flatten().cuda()] = -lat[0, blk.flatten().cuda()]
+    kw = dict(image=img, prompt_embeds=prompt, pooled_prompt_embeds=y, height=h * 16, width=w * 16, latents=lat, return_dict=False)
+    if family == "flux":
+        kw.update(guidance_scale=2.5)
+    else:
+        kw.update(negative_prompt_embeds=nprompt, negative_pooled_prompt_embeds=ny, true_cfg_scale=4.0)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    res = {}
+    for skip in (True, False):
+        monkeypatch.setattr(H, "SKIP_UNREAD_ROWS", skip)
+        van = pipe(**kw)[0].clone()
+        helper.enable()
+        reg = pipe(**kw)[0].clone()
+        ids = pipe._regione_manager.edited_ids.clone()
+        helper.disable()
+        res[skip] = (van, reg, ids)
+    assert torch.equal(res[True][2], res[False][2])
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert 0 < res[True][2].numel() < h * w
+    if family == "flux":
+        monkeypatch.setattr(H, "SKIP_UNREAD_ROWS", True)
+        tr = pipe.transformer
+        x = torch.cat([lat, img], 1)
+        a = dict(hidden_states=x, timestep=torch.tensor([0.5], dtype=torch.bfloat16), guidance=torch.tensor([2.5]),
+                 pooled_projections=y, encoder_hidden_states=prompt, txt_ids=torch.zeros(32, 3), img_ids=synth.flux_latent_ids(h, w),
+                 return_dict=False)
+        full = tr(**a)[0]
+        tr.out_rows_hint = h * w
+        part = tr(**a)[0]
+        assert full.shape[1] == 2 * h * w and part.shape[1] == h * w and torch.equal(full[:, : h * w], part)
+        assert tr(**a)[0].shape[1] == 2 * h * w          # the hint is one-shot
