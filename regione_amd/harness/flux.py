@@ -241,10 +241,27 @@ class FluxAttnProcessor:
         # partial K/V update (region step): the rows the reference sends through `_partially_linear` round fp32 -> fp16 ->
         # bf16 (fused_kernels.py:80, quirk A-3): every row of a single-stream block, the image rows of a double-stream one
         partial = kv_rows is not None
+        ctx.partial_kv = partial
         if fuse:
             epi = dict(rope_q=image_rotary_emb, rope_k=rope_k, k_slab=k_slab, vt_slab=vt_slab, H=H, k_col=0, v_col=d,
                        q_col=2 * d, kv_rows=kv_rows)
+        n_out = ctx.out_rows if (block is not None and getattr(block, "is_last", False)) else None
         if not self.single:
+            if n_out is not None and not partial:
+                # last block of a double-stream-only trunk (Qwen-Image), full step: keys / values of every row of both
+                # streams, but queries, attention and the output projection only for the image rows the caller reads; the
+                # text stream's output of this block feeds nothing
+                lo, hi = T, T + n_out
+                ops.gemm_pair(ws.nrm[T:R], attn.w_kvq[:2 * d], attn.b_kvq[:2 * d], wide[T:R, :2 * d],
+                              ws.nrm[:T], attn.w_add_kvq[:2 * d], attn.b_add_kvq[:2 * d], wide[:T, :2 * d])
+                ops.gemm(ws.nrm[lo:hi], attn.w_kvq[2 * d:], attn.b_kvq[2 * d:], wide[lo:hi, 2 * d:3 * d])
+                ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
+                                       k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
+                q = wide[lo:hi, 2 * d:3 * d]
+                ops.attention(q, k_slab, vt_slab, q, skv, H)
+                g_img, _ = block.gates_msa(ctx)
+                ops.gemm(q, attn.w_out, attn.b_out, ws.x[lo:hi], epilogue=ops.EPI_GATE_RESID, gate=g_img, resid=ws.x[lo:hi])
+                return ws.x[T:R], ws.x[:T]
             if fuse:       # projections + RMSNorm + RoPE + K / V^T cache placement of both streams: ONE launch
                 ops.gemm_qkv_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
                                   ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, row_base=T, fp16_roundtrip=partial, **epi),
@@ -262,8 +279,7 @@ class FluxAttnProcessor:
                           epilogue=ops.EPI_GATE_RESID, gate0=g_img, resid0=ws.x[T:R], gate1=g_txt, resid1=ws.x[:T])
             return ws.x[T:R], ws.x[:T]
         # single stream: one GEMM produces [k | v | q | gelu(mlp)] from the same normed activations
-        n_out = ctx.out_rows if (block is not None and getattr(block, "is_last", False)) else None
-        if n_out is not None and n_out < M and not partial:
+        if n_out is not None and not partial:
             # last block of a full step: keys / values of every row, but queries, MLP, attention and (in the block)
             # proj_out only for the rows the caller reads - the text and condition-image rows of this block's output feed
             # nothing.  (Region steps keep the one-launch path: their K/V rows carry the fp16 round trip of quirk A-3.)
@@ -311,6 +327,14 @@ class FluxTransformerBlock:
                         shift0=mods.chunk(self.mo_ctx, 0), scale0=mods.chunk(self.mo_ctx, 1))
         self.attn(hidden_states=ws.nrm[T:R], encoder_hidden_states=ws.nrm[:T], image_rotary_emb=image_rotary_emb,
                   ctx=ctx, block=self)
+        if getattr(self, "is_last", False) and ctx.out_rows is not None and not getattr(ctx, "partial_kv", False):
+            lo, hi = T, T + ctx.out_rows                      # only these rows of the trunk's output are read
+            ops.ln_modulate(ws.x[lo:hi], ws.nrm[lo:hi], mods.chunk(self.mo_img, 3), mods.chunk(self.mo_img, 4))
+            ffh = ws.wide[:R, 3 * d:]
+            ops.gemm(ws.nrm[lo:hi], self.ff_w1, self.ff_b1, ffh[lo:hi], epilogue=ops.EPI_GELU)
+            ops.gemm(ffh[lo:hi], self.ff_w2, self.ff_b2, ws.x[lo:hi], epilogue=ops.EPI_GATE_RESID,
+                     gate=mods.chunk(self.mo_img, 5), resid=ws.x[lo:hi])
+            return ws.x[:T], ws.x[T:R]
         # norm2 + FF with the gated residual fused into the second GEMM
         ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo_img, 3), mods.chunk(self.mo_img, 4), split_row=T,
                         shift0=mods.chunk(self.mo_ctx, 3), scale0=mods.chunk(self.mo_ctx, 4))
@@ -365,6 +389,8 @@ class FluxTransformer2DModel:
             off += 3 * d
         if self.single_transformer_blocks:
             self.single_transformer_blocks[-1].is_last = True       # its output feeds only norm_out / proj_out
+        elif self.transformer_blocks:
+            self.transformer_blocks[-1].is_last = True              # double-stream-only trunk (Qwen-Image)
         self.mo_out = off
         self.mod_total = off + 2 * d
         self.ws = Workspace(cfg, self.device)
@@ -555,7 +581,7 @@ class FluxTransformer2DModel:
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
-        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo)
+        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo if SKIP_UNREAD_ROWS else None)
         for block in self.transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
         for block in self.single_transformer_blocks:

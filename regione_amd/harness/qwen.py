@@ -129,6 +129,7 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             def branch(embeds, tag):
+                tr.out_rows_hint = latents.size(1)
                 return tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=embeds, img_shapes=img_shapes,
                           latent_ids=latent_ids, attention_kwargs={"tag": tag}, return_dict=False)[0][:, : latents.size(1)]
             if do_true_cfg:

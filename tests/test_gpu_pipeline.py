@@ -533,7 +533,7 @@ def test_degenerate_partitions_nothing_or_everything_edited(threshold, expect):
     assert "".join(trace["kind"]) == "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04)).replace("S", "F")
 
 
-@pytest.mark.parametrize("family", ["flux", "step1x_v1p2"])
+@pytest.mark.parametrize("family", ["flux", "step1x_v1p2", "qwen"])
 def test_last_block_skips_rows_nothing_reads_same_result(family, monkeypatch):
     """harness/flux.py `out_rows`: the pipelines read only `[:, :latents.size(1)]` of a forward, so in a full step the last
     single block computes queries / MLP / attention / proj_out (and norm_out / proj_out) for the latent rows only.  Same
@@ -545,21 +545,29 @@ def test_last_block_skips_rows_nothing_reads_same_result(family, monkeypatch):
         cfg = synth.FluxConfig(**synth.TOY)
         wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
         pipe = _toy_pipe({k: v.cuda() for k, v in wts.items()}, cfg)
+    elif family == "qwen":
+        from regione_amd.harness import qwen as HQ
+        cfg = synth.FluxConfig(**synth.QWEN_TOY)
+        wts = synth.make_flux_weights(cfg, seed=6, dtype=torch.bfloat16, w_std=0.05)
+        pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, "cuda").load_state_dict(wts))
     else:
         cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
         wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
         pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts))
-    lat, img, prompt, y = [t.cuda() for t in synth.make_edit_inputs(h, w, 32, cfg, seed=9, dtype=torch.bfloat16)]
-    _, _, nprompt, ny = [t.cuda() if t is not None else None for t in synth.make_edit_inputs(h, w, 24, cfg, seed=10, dtype=torch.bfloat16)]
+    cu = lambda t: t.cuda() if t is not None else None
+    lat, img, prompt, y = [cu(t) for t in synth.make_edit_inputs(h, w, 32, cfg, seed=9, dtype=torch.bfloat16)]
+    _, _, nprompt, ny = [cu(t) for t in synth.make_edit_inputs(h, w, 24, cfg, seed=10, dtype=torch.bfloat16)]
     blk = torch.zeros(h, w, dtype=torch.bool)
     blk[4:10, 5:12] = True                                   # a region by construction: condition == start latents outside it
     img = lat.clone()
     img[0, blk.flatten().cuda()] = -lat[0, blk.flatten().cuda()]
-    kw = dict(image=img, prompt_embeds=prompt, pooled_prompt_embeds=y, height=h * 16, width=w * 16, latents=lat, return_dict=False)
+    kw = dict(image=img, prompt_embeds=prompt, height=h * 16, width=w * 16, latents=lat, return_dict=False)
     if family == "flux":
-        kw.update(guidance_scale=2.5)
+        kw.update(pooled_prompt_embeds=y, guidance_scale=2.5)
+    elif family == "qwen":
+        kw.update(negative_prompt_embeds=nprompt, true_cfg_scale=4.0)
     else:
-        kw.update(negative_prompt_embeds=nprompt, negative_pooled_prompt_embeds=ny, true_cfg_scale=4.0)
+        kw.update(pooled_prompt_embeds=y, negative_prompt_embeds=nprompt, negative_pooled_prompt_embeds=ny, true_cfg_scale=4.0)
     helper = RegionEHelper(pipe)
     helper.set_params(threshold=0.5)
     res = {}
