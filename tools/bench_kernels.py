@@ -124,7 +124,11 @@ def bench_region():
 
 
 def bench_attn():
-    for name, Sq, Skv, H in [("full", 8704, 8704, 24), ("region 25%", 1536, 8704, 24), ("region 5%", 717, 8704, 24)]:
+    shapes = [("full", 8704, 8704, 24), ("region 25%", 1536, 8704, 24), ("region 5%", 717, 8704, 24)]
+    if os.environ.get("ATTN_MORE"):       # other families' region steps: Qwen uncond branch, Step1X v1p2 2048^2, K_e 15 / 50 %
+        shapes += [("qwen R T384", 1408, 8576, 24), ("v1p2 2048 R", 4608, 33280, 24), ("region 15%", 1137, 8704, 24),
+                   ("region 50%", 2537, 8704, 24)]
+    for name, Sq, Skv, H in shapes:
         D = H * 128
         q, k, vt = rnd(Sq, D), rnd(Skv, D), rnd(D, Skv)
         out = torch.empty_like(q)
