@@ -77,6 +77,19 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 
 __device__ __forceinline__ size_t kvpos(size_t r) { return (r & ~(size_t)12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
+// value of lane (l ^ X) for X in {1, 2, 4, 8}, exchanged inside the 16-lane DPP row
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int X>
+__device__ __forceinline__ float lane_xor(float x) {
+    if constexpr (X == 1) return dpp_mov<0xB1>(x);                      // quad_perm:[1,0,3,2]
+    else if constexpr (X == 2) return dpp_mov<0x4E>(x);                 // quad_perm:[2,3,0,1]
+    else if constexpr (X == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(x)); // row_half_mirror (l ^ 7) then quad_perm:[3,2,1,0] (l ^ 3)
+    else return dpp_mov<0x128>(x);                                      // row_ror:8 == l ^ 8 inside a 16-lane row
+}
+
 // Per-head RMSNorm + RoPE of 8 consecutive columns of one row (16 lanes = one 128-wide head).  Same
 // arithmetic and the SAME summation tree as qk_norm_rope_kernel (norm.hip), so both paths agree bit for bit.
 struct RopeTab { float4 c0, c1, s0, s1; };
@@ -95,10 +108,16 @@ __device__ __forceinline__ void qk_norm_rope_vec(uint16_t (&v)[8], const uint16_
     for (int e = 0; e < 8; ++e) x[e] = bf2f(v[e]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) p[j] = x[2 * j] * x[2 * j] + x[2 * j + 1] * x[2 * j + 1];
+    // butterfly over the 16 lanes of a head (partners lane ^ 8, ^ 4, ^ 2, ^ 1) as DPP moves inside the 16-lane row -
+    // the generic __shfl_xor goes through the LDS crossbar (ds_bpermute): 256 of them per thread and tile
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1)
+    for (int j = 0; j < 4; ++j) p[j] += lane_xor<8>(p[j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) p[j] += __shfl_xor(p[j], o, 64);
+    for (int j = 0; j < 4; ++j) p[j] += lane_xor<4>(p[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] += lane_xor<2>(p[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) p[j] += lane_xor<1>(p[j]);
     const float ss = (p[0] + p[2]) + (p[1] + p[3]);
     const float r = 1.0f / sqrtf(ss * (1.0f / 128.0f) + eps);
     const float cc[8] = {t.c0.x, t.c0.y, t.c0.z, t.c0.w, t.c1.x, t.c1.y, t.c1.z, t.c1.w};
