@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Shader clock / power under sustained load of one kernel (GPU box only): queues ~2 s of back-to-back
-launches and polls rocm-smi while the GPU drains them.   python tools/clock_probe.py [attn|gemm|idle]"""
+launches and polls rocm-smi while the GPU drains them.   python tools/clock_probe.py [attn|gemm|vendor|idle]"""
 import sys, os, subprocess, time, re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,6 +27,10 @@ def main():
         A, W, b = rnd(8704, 3072), rnd(21504, 3072) * 0.05, rnd(21504)
         out = torch.empty(8704, 21504, dtype=torch.bfloat16, device="cuda")
         fn, n = (lambda: ops.gemm(A, W, b, out)), 2000
+    elif what == "vendor":          # reference point: the vendor library's kernel on the same shape (hipBLASLt via torch.addmm)
+        A, W, b = rnd(8704, 3072), rnd(21504, 3072) * 0.05, rnd(21504)
+        out = torch.empty(8704, 21504, dtype=torch.bfloat16, device="cuda")
+        fn, n = (lambda: torch.addmm(b, A, W.t(), out=out)), 2000
     else:
         fn, n = (lambda: None), 0
     print("idle     sclk/mclk/W:", smi())
