@@ -64,6 +64,54 @@ def cosine_rows(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:
     return torch.sum(F.normalize(t1, dim=-1) * F.normalize(t2, dim=-1), dim=-1)
 
 
+def cosine_rows_explicit(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:
+    """The same quantity as cosine_rows() for rows of 64 channels with every floating-point rounding and every
+    reduction tree written out (numpy, no torch reductions).  torch eager's CPU kernels reduce a contiguous last
+    dimension of 64 with FIXED trees; `similarity <= threshold` (utils.py:333) is only reproducible bit for bit by a
+    kernel that follows them, so they are pinned here (tests/test_oracle_golden.py checks this function against torch
+    and against the reference-generated fixtures, incl. the +-4-ulp adversarial rows of arp_adv.npz):
+      * fp32 L2 norm (F.normalize -> linalg_vector_norm): 8 lanes, acc[j] = x[j]^2, acc[j] = fma(x[8b+j], x[8b+j], acc[j])
+        for b = 1..7, lanes added left to right, sqrt;
+      * bf16 L2 norm: fp32 squares (exact), xor butterfly over 64 lanes with strides 32, 16, 8, 4, 2, 1, sqrt, result
+        rounded to bf16; the quotient is rounded to bf16 again;
+      * torch.sum of the fp32 products: 8-lane vectors v0..v7, t[k] = v[k] + v[k+4], a = ((t0 + t1) + t2) + t3, lanes
+        added left to right."""
+    f32, f64 = np.float32, np.float64
+    assert t1.dtype == torch.float32 and t1.shape[-1] == 64
+
+    def seq(v):
+        acc = v[:, 0].copy()
+        for j in range(1, v.shape[1]):
+            acc = acc + v[:, j]
+        return acc
+
+    def norm_f32(x):
+        acc = x[:, :8] * x[:, :8]
+        for b in range(1, 8):
+            xb = x[:, 8 * b: 8 * b + 8].astype(f64)
+            acc = (acc.astype(f64) + xb * xb).astype(f32)       # fused multiply-add (one rounding)
+        return np.sqrt(seq(acc))
+
+    def rbf(x):
+        return torch.from_numpy(np.ascontiguousarray(x)).to(torch.bfloat16).float().numpy()
+
+    x = t1.reshape(-1, 64).numpy()
+    a = x / np.maximum(norm_f32(x), f32(1e-12))[:, None]
+    if t2.dtype == torch.bfloat16:
+        c = t2.reshape(-1, 64).float().numpy()
+        v = c * c
+        for o in (32, 16, 8, 4, 2, 1):
+            v = v + v[:, np.arange(64) ^ o]
+        n2 = np.maximum(rbf(np.sqrt(v[:, 0])), rbf(np.array([1e-12], f32)))
+        b = rbf(c / n2[:, None])
+    else:
+        c = t2.reshape(-1, 64).numpy()
+        b = c / np.maximum(norm_f32(c), f32(1e-12))[:, None]
+    p = a * b
+    t = [p[:, 8 * k: 8 * k + 8] + p[:, 8 * (k + 4): 8 * (k + 4) + 8] for k in range(4)]
+    return torch.from_numpy(seq(((t[0] + t[1]) + t[2]) + t[3])).reshape(t1.shape[:-1])
+
+
 def erode_cross3(mask: np.ndarray) -> np.ndarray:
     """utils.py:152-179 with the 3x3 cross kernel of utils.py:228: a pixel survives iff it and
     its 4-neighbours are all set; zero padding => the outermost ring never survives."""

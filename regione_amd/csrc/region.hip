@@ -15,6 +15,40 @@ template <typename T> __device__ __forceinline__ float ld_as_f32(const T* p, siz
 template <> __device__ __forceinline__ float ld_as_f32<float>(const float* p, size_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ld_as_f32<uint16_t>(const uint16_t* p, size_t i) { return bf2f(p[i]); }
 
+// torch-CPU reduction trees over a 64-element row held one element per lane.  The reference runs on torch eager; its CPU
+// kernels (the parity oracle) reduce a contiguous last dimension of 64 with FIXED trees, reproduced here bit for bit
+// (tests/test_host_logic.py::test_torch_cpu_reduction_trees pins them against torch itself):
+//   * torch.sum (SumKernel.cpp vectorized_inner_sum, 8-float vectors, 4 interleaved accumulators):
+//       t[k][j] = p[8k+j] + p[8(k+4)+j] (k < 4, j < 8);  a[j] = ((t[0][j] + t[1][j]) + t[2][j]) + t[3][j];
+//       sum = (((a[0] + a[1]) + a[2]) + ... + a[7])
+//   * fp32 norm (F.normalize -> linalg_vector_norm): acc[j] = x[j]^2, then acc[j] = fma(x[8b+j], x[8b+j], acc[j]) for
+//       b = 1..7 (the compiler contracts the accumulate), sum = ((acc[0] + acc[1]) + ... + acc[7]), sqrt
+//   * bf16 norm (fp32 accumulate, squares exact): xor butterfly 32, 16, 8, 4, 2, 1 == wave_sum()
+__device__ __forceinline__ float row_sum_torch(float p, int lane) {
+    const int j = lane & 7;
+    const float t = p + __shfl_xor(p, 32, 64);
+    const float a = ((__shfl(t, j, 64) + __shfl(t, 8 + j, 64)) + __shfl(t, 16 + j, 64)) + __shfl(t, 24 + j, 64);
+    float s = __shfl(a, 0, 64);
+#pragma unroll
+    for (int l = 1; l < 8; ++l) s = s + __shfl(a, l, 64);
+    return s;
+}
+
+__device__ __forceinline__ float row_sumsq_torch_f32(float x, int lane) {
+    const int j = lane & 7;
+    const float x0 = __shfl(x, j, 64);
+    float acc = __fmul_rn(x0, x0);
+#pragma unroll
+    for (int b = 1; b < 8; ++b) {
+        const float xb = __shfl(x, 8 * b + j, 64);
+        acc = __builtin_fmaf(xb, xb, acc);
+    }
+    float s = __shfl(acc, 0, 64);
+#pragma unroll
+    for (int l = 1; l < 8; ++l) s = s + __shfl(acc, l, 64);
+    return s;
+}
+
 template <typename TS, typename TM, typename TC>
 __global__ __launch_bounds__(256) void arp_sim_kernel(const TS* __restrict__ sample, const TM* __restrict__ mo,
                                                       const TC* __restrict__ cond, float dt_final, float thr,
@@ -35,7 +69,7 @@ __global__ __launch_bounds__(256) void arp_sim_kernel(const TS* __restrict__ sam
         est = __fadd_rn(est, p);
     }
     // F.normalize(est): fp32 norm, clamp_min(1e-12), divide
-    float n1 = sqrtf(wave_sum(__fmul_rn(est, est)));
+    float n1 = sqrtf(row_sumsq_torch_f32(est, lane));
     float a = est / fmaxf(n1, 1e-12f);
     float b;
     if constexpr (sizeof(TC) == 2) {
@@ -46,10 +80,10 @@ __global__ __launch_bounds__(256) void arp_sim_kernel(const TS* __restrict__ sam
         b = rbf(c / n2);
     } else {
         float c = cond[i];
-        float n2 = sqrtf(wave_sum(__fmul_rn(c, c)));
+        float n2 = sqrtf(row_sumsq_torch_f32(c, lane));
         b = c / fmaxf(n2, 1e-12f);
     }
-    float s = wave_sum(__fmul_rn(a, b));
+    float s = row_sum_torch(__fmul_rn(a, b), lane);
     if (lane == 0) {
         raw[tok] = (s <= thr) ? 1 : 0;                        // utils.py:333
         if (sim_out) sim_out[tok] = s;

@@ -1,0 +1,134 @@
+"""-m gpu: BASELINE.json configs[3] and configs[4] at their full sizes (synthetic weights at the public dimensions, region
+fixed by construction), through size-independent properties - the oracle cannot run these sizes in seconds.
+
+  configs[3]  FLUX.1-Kontext 1024^2, true CFG 6.0 (one rank's image of the 8-way batch sharding; the sharding itself is
+              covered by tests/test_multiproc_gloo.py and bench.py --gpus N --true-cfg 6.0)
+  configs[4]  Step1X-Edit v1p2 2048^2 (L = 16384), 50 steps, cache_threshold 0.02 - the reference refuses N != 28
+              (utils.py:391), so the decay table is the family's table re-sampled to 49 entries (gamma="resample")
+"""
+import pytest
+import torch
+
+from oracle import regione_oracle as O
+from regione_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _ids_partition_ok(M, h, w, box):
+    from tools.run_configs import expected_ids
+    e, u = M.edited_ids.squeeze(0).cpu(), M.unedited_ids.squeeze(0).cpu()
+    assert torch.equal(e, expected_ids(h, w, box))
+    assert torch.equal(torch.sort(torch.cat([e, u])).values, torch.arange(h * w))
+    return e
+
+
+def test_config3_flux_1024_true_cfg6_full_size(golden):
+    """Two forwards per computed step.  Default: one K/V cache per branch tag (the fix Qwen / Step1X-v1p2 apply);
+    strict_reference=True: ONE cache shared by both branches like the reference (quirk A-4, inplace.py:700-702)."""
+    import bench as B
+    from regione_amd import RegionEHelper
+    from regione_amd.harness import flux as HF
+    from tools.run_configs import weights_stream, make_box
+    dev = torch.device("cuda", 0)
+    cfg = synth.FluxConfig()
+    pipe = HF.FluxKontextPipeline(HF.FluxTransformer2DModel(cfg, dev).load_state_dict_stream(weights_stream(cfg, dev, 42)))
+    h = w = 64
+    L, T = h * w, 512
+    lat, img, prompt, pooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, T, cfg, seed=110)]
+    _, _, nprompt, npooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, T, cfg, seed=111)]
+    box = make_box(h, w, 0.25)
+    plan_ref = "".join(golden("loop_plan_64")["kinds"].tolist())
+    outs = {}
+    for strict in (False, True):
+        helper = RegionEHelper(pipe)
+        helper.set_params(threshold=0.88, cache_threshold=0.04, strict_reference=strict)
+        helper.enable()
+        B.install_region_injection(pipe, h, w, box, img[0:1], seed=7)
+        trace = {}
+        out = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=1024, width=1024, latents=lat,
+                   guidance_scale=2.5, true_cfg_scale=6.0, negative_prompt_embeds=nprompt,
+                   negative_pooled_prompt_embeds=npooled, return_dict=False, trace=trace)[0]
+        M = pipe._regione_manager
+        assert "".join(trace["kind"]) == plan_ref                    # the reference-run plan at L = 4096
+        e = _ids_partition_ok(M, h, w, box)
+        lens = [x.shape[1] for x in trace["latents"]]
+        assert lens == [L if n == L else e.numel() for n in golden("loop_plan_64")["len"].tolist()]
+        blocks = list(pipe.transformer.transformer_blocks) + list(pipe.transformer.single_transformer_blocks)
+        ncache = {len(b.attn.processor.caches) for b in blocks}
+        assert ncache == ({1} if strict else {2}), ncache
+        assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
+        outs[strict] = out.cpu()
+        helper.disable()
+    # the two cache policies are different computations (the shared cache holds the UNCOND branch's K/V) but the same
+    # edit: close, not identical
+    assert not torch.equal(outs[True], outs[False])
+    del pipe
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_config4_step1x_v1p2_2048_50_steps(golden, weights):
+    """L = L_c = 16384 (S = 33280 / 33152 rows per branch), 50 denoising steps, tagged sequential CFG 6.0 with text
+    lengths 512 / 384, one K/V cache per branch (2 x 23 GB).  `weights="fp8"`: the trunk's GEMM weights are OCP e4m3
+    with per-output-channel scales (BASELINE configs[4] "fp8 weights"), activations stay bf16."""
+    import bench as B
+    from regione_amd import RegionEHelper
+    from regione_amd.harness import step1x as HS
+    from regione_amd.tool.RegionE import resample_gamma
+    from tools.run_configs import weights_stream, make_box
+    dev = torch.device("cuda", 0)
+    cfg = synth.FluxConfig(guidance_embeds=False)
+    tr = HS.Step1XEditTransformer2DModel(cfg, dev).load_state_dict_stream(weights_stream(cfg, dev, 42))
+    if weights == "fp8":
+        if not hasattr(tr, "quantize_fp8_"):
+            pytest.skip("fp8 weight path not built")
+        tr.quantize_fp8_()
+    pipe = HS.Step1XEditPipelineV1P2(tr)
+    h = w = 128
+    L, T, Tn, N = h * w, 512, 384, 50
+    lat, img, prompt, pooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, T, cfg, seed=110)]
+    _, _, nprompt, npooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, Tn, cfg, seed=111)]
+    kw = dict(num_inference_steps=N, gamma="resample", warmup_step=10, post_step=4, refresh_step="28", cache_threshold=0.02)
+    helper = RegionEHelper(pipe)
+    helper.set_params(**kw)
+    helper.enable()
+    box = make_box(h, w, 0.25)
+    B.install_region_injection(pipe, h, w, box, img[0:1], seed=7)
+    trace = {}
+    out = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, negative_prompt_embeds=nprompt,
+               negative_pooled_prompt_embeds=npooled, true_cfg_scale=6.0, height=2048, width=2048, latents=lat,
+               num_inference_steps=N, return_dict=False, trace=trace)[0]
+    M = pipe._regione_manager
+    kinds = "".join(trace["kind"])
+    # plan = the reference's decision logic (oracle.derive_schedule, pinned against the reference-run plans incl.
+    # s1xv2_plan_128 at this L for N = 28) evaluated with the re-sampled table
+    gam = resample_gamma(O.GAMMA["step1x_v1p2"], N)
+    plan = "".join(O.derive_schedule(L, "step1x_v1p2", 10, 4, "28", 0.02, n=N, gamma=gam)).replace("S", "F")
+    assert kinds == plan and len(kinds) == N
+    assert kinds.count("F") == 10 + 1 + 4 and kinds[9] == "F" and kinds[27] == "F"
+    e = _ids_partition_ok(M, h, w, box)
+    K = e.numel()
+    # sequence lengths: full until the partition (step warmup-1), K_e between, full at the refresh step and for the tail
+    lens = [x.shape[1] for x in trace["latents"]]
+    want = [L] * 9 + [K] * 17 + [L] + [K] * 18 + [L] * 5
+    assert lens == want, (lens, want)
+    # a cache-served step is EXACTLY cached velocity x decay ratio
+    from regione_amd import ops
+    ts = pipe.scheduler.timesteps.float().cpu()
+    last, checked = None, 0
+    for i, k in enumerate(kinds):
+        v = trace["noise_pred"][i]
+        if k == "C":
+            ratio = gam[i - 1] * (1 + (ts[i] - ts[i - 1]) / 1000)
+            src = last if last.shape[1] == v.shape[1] else ops.gather_rows(last, M.edited_ids)
+            assert torch.equal(v, ops.avd_apply(src, float(ratio))), i
+            checked += 1
+        else:
+            last = v
+    assert checked == kinds.count("C")
+    blocks = list(pipe.transformer.transformer_blocks) + list(pipe.transformer.single_transformer_blocks)
+    assert {len(b.attn.processor.caches) for b in blocks} == {2}
+    assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
+    del pipe, tr
+    torch.cuda.empty_cache()

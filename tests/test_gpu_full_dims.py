@@ -1,0 +1,159 @@
+"""-m gpu: the masked MMDiT block at FLUX.1-Kontext's REAL dimensions against the oracle.
+
+One double-stream + one single-stream block at d = 3072, 24 heads x 128, d_ff = 12288, T = 512 text rows, L = L_c = 4096
+(S = 8704 rows), bf16 - the same tensors on both sides:
+
+  * FULL step with K/V store (reference inplace.py:721-725): trunk output, and every row of each layer's K slab and
+    V^T slab against the oracle's raw cache pushed through the oracle's RMSNorm + RoPE (the engine caches K post-norm /
+    post-RoPE and V transposed - DESIGN.md section 2);
+  * REGION step (inplace.py:727-750; K_e = 1024 edited tokens, partial K/V update with the fp16 round trip of
+    fused_kernels.py:80): trunk output for the T + K_e computed rows, the rewritten cache rows, and the untouched
+    cache rows bit-for-bit unchanged.
+
+Tolerance (bf16 arithmetic on both sides, different GEMM accumulation orders): PSNR >= 40 dB and relative L2 error
+< 1e-2 on every compared tensor.  The oracle runs torch-CPU bf16 eager, i.e. the dtype path the reference itself runs.
+"""
+import pytest
+import torch
+
+from oracle import regione_oracle as O
+from regione_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / b.norm())
+
+
+def _check(name, got, ref, min_psnr=40.0, max_rel=1e-2):
+    p, r = O.psnr(got.float().cpu(), ref.float().cpu()), _rel(got.cpu(), ref.cpu())
+    print(f"[full-dims parity] {name}: PSNR {p:.1f} dB, rel L2 {r:.2e}")
+    assert p >= min_psnr and r < max_rel, f"{name}: PSNR {p:.1f} dB, rel {r:.2e}"
+    return p, r
+
+
+def _slabs(proc, tag, S, H):
+    """(K [H, S, 128] post-norm/post-RoPE, V [H, S, 128]) from a processor's slabs (V^T slab un-permuted)."""
+    k_slab, vt_slab, skv = proc.caches[tag]
+    assert skv == S
+    r = torch.arange(S)
+    pos = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+    k = k_slab[:S].cpu().view(S, H, 128).transpose(0, 1)
+    v = vt_slab.cpu()[:, pos].view(H, 128, S).permute(0, 2, 1)
+    return k, v
+
+
+def _oracle_kv(w, prefix, cache, heads, T, rope_k, double):
+    """Oracle raw cache -> what attention consumes: RMSNorm + RoPE on K (inplace.py:760-794), V as is.  Double-stream
+    caches hold the image rows only (the text K/V are recomputed every step), single-stream ones all rows."""
+    a = prefix + ".attn."
+    k = cache.k.view(1, -1, heads, 128).transpose(1, 2)
+    v = cache.v.view(1, -1, heads, 128).transpose(1, 2)
+    k = O.rms_norm(k, w[a + "norm_k.weight"])
+    cos, sin = rope_k
+    if double:
+        cos, sin = cos[T:], sin[T:]
+    return O.apply_rope(k, cos, sin)[0], v[0]
+
+
+def test_flux_full_dims_double_and_single_block_full_store_then_region_update():
+    from regione_amd import RegionEHelper
+    from regione_amd.harness import flux as H
+    dev = torch.device("cuda", 0)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    cfg = synth.FluxConfig(n_double=1, n_single=1)
+    assert cfg.d == 3072 and cfg.heads == 24
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16)
+    h = w = 64
+    T, L, heads = 512, 64 * 64, cfg.heads
+    S = T + 2 * L
+    lat, img, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=9)
+    guidance = torch.full([1], 2.5, dtype=torch.float32)
+
+    # ---- HIP engine through the reference's hook points ------------------------------------------------
+    tr = H.FluxTransformer2DModel(cfg, dev).load_state_dict(wts)
+    pipe = H.FluxKontextPipeline(tr)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.88)
+    helper.enable()
+    M = pipe._regione_manager
+    latents, image_latents, latent_ids, text_ids, _, _ = pipe.prepare(img, prompt, pooled, 1024, 1024, lat, None, 28)
+    M.refresh(latents, image_latents, latent_ids, text_ids, 2, 8, 1024, 1024)
+    ts = pipe.scheduler.timesteps
+    prompt_d, pooled_d = prompt.to(dev), pooled.to(dev)
+
+    def hip_forward(x, ids, step):
+        M.current_step = step
+        t = ts[step].expand(1).to(torch.bfloat16)
+        out = pipe.transformer(hidden_states=x, timestep=t / 1000, guidance=guidance, pooled_projections=pooled_d,
+                               encoder_hidden_states=prompt_d, txt_ids=text_ids, img_ids=ids,
+                               joint_attention_kwargs={"tag": "cond"}, return_dict=False)[0]
+        torch.cuda.synchronize()
+        return out
+
+    # ---- oracle state ------------------------------------------------------------------------------------
+    ocfg = O.FluxCfg(n_double=1, n_single=1)
+    st = O.RegionState()
+    st.set_parameters(28, 6, 2, "16", 0.88, 0.04, True)
+    ids_full = synth.flux_latent_ids(h, w)
+    st.refresh(img, ids_full, T, h, w)
+    caches = [O.KVCache(), O.KVCache()]
+    txt_ids = torch.zeros(T, 3)
+    _, ots = O.flow_match_schedule(28, L)
+    assert torch.equal(ots, ts.cpu())
+
+    def oracle_forward(x, ids, step):
+        st.current_step = step
+        t = ots[step].expand(1).to(torch.bfloat16)
+        with torch.no_grad():
+            return O.transformer_forward(wts, ocfg, st, caches, x, prompt, pooled, t / 1000, ids, txt_ids, guidance)
+
+    # ---- FULL step + store (step warmup-1) -----------------------------------------------------------------
+    x_full = torch.cat([lat, img], dim=1)
+    store = M.warmup_step - 1
+    out_hip = hip_forward(x_full.to(dev), latent_ids, store)
+    out_ref = oracle_forward(x_full, ids_full, store)
+    assert out_hip.shape == out_ref.shape == (1, 2 * L, 64)
+    _check("full-step output", out_hip, out_ref)
+    rope_k = O.flux_pos_embed(torch.cat((txt_ids, ids_full), 0), ocfg.axes_dim)
+    procs = [pipe.transformer.transformer_blocks[0].attn.processor, pipe.transformer.single_transformer_blocks[0].attn.processor]
+    prefixes = ["transformer_blocks.0", "single_transformer_blocks.0"]
+    stored = []
+    for proc, prefix, cache, double in zip(procs, prefixes, caches, (True, False)):
+        k_hip, v_hip = _slabs(proc, "cond", S, heads)
+        k_ref, v_ref = _oracle_kv(wts, prefix, cache, heads, T, rope_k, double)
+        lo = T if double else 0                      # the oracle's double-stream cache holds image rows only
+        _check(prefix + " K slab (store)", k_hip[:, lo:], k_ref)
+        _check(prefix + " V^T slab (store)", v_hip[:, lo:], v_ref)
+        stored.append((k_hip.clone(), v_hip.clone()))
+
+    # ---- REGION step (step warmup): K_e = 1024 edited tokens, partial K/V update -------------------------------
+    box = torch.zeros(h, w, dtype=torch.bool)
+    box[16:48, 16:48] = True
+    e = torch.nonzero(box.flatten()).squeeze(1)
+    u = torch.nonzero(~box.flatten()).squeeze(1)
+    assert e.numel() == 1024
+    M.set_partition(e.unsqueeze(0).to(dev), u.unsqueeze(0).to(dev), box.flatten().to(torch.uint8).to(dev))
+    st.edited_ids, st.unedited_ids = e.unsqueeze(0), u.unsqueeze(0)
+    g = torch.Generator().manual_seed(77)
+    lat_e = torch.randn(1, e.numel(), 64, generator=g).to(torch.bfloat16)          # fresh edited-token latents
+    ids_e = ids_full[e]
+    out_hip = hip_forward(lat_e.to(dev), latent_ids[e], M.warmup_step)
+    out_ref = oracle_forward(lat_e, ids_e, st.warmup_step)
+    assert out_hip.shape == out_ref.shape == (1, e.numel(), 64)
+    _check("region-step output", out_hip, out_ref)
+    for proc, prefix, cache, double, (k0, v0) in zip(procs, prefixes, caches, (True, False), stored):
+        k_hip, v_hip = _slabs(proc, "cond", S, heads)
+        k_ref, v_ref = _oracle_kv(wts, prefix, cache, heads, T, rope_k, double)
+        lo = T if double else 0
+        _check(prefix + " K slab (after update)", k_hip[:, lo:], k_ref)
+        _check(prefix + " V^T slab (after update)", v_hip[:, lo:], v_ref)
+        rows = T + e                                                     # rewritten image rows
+        _check(prefix + " rewritten K rows", k_hip[:, rows], k_ref[:, rows - lo])
+        _check(prefix + " rewritten V rows", v_hip[:, rows], v_ref[:, rows - lo])
+        # rows the region step must not touch: condition-image rows and unedited noise rows stay bit-identical
+        keep = torch.cat([T + u, T + L + torch.arange(L)])
+        assert torch.equal(k_hip[:, keep], k0[:, keep]) and torch.equal(v_hip[:, keep], v0[:, keep]), prefix
+        assert not torch.equal(k_hip[:, rows], k0[:, rows])

@@ -112,6 +112,79 @@ def gen_arp(ns):
     save("arp", d)
 
 
+def gen_arp_adv(ns):
+    """Adversarial partition cases (SURVEY.md section 7 hard-part 1 / 8c G1): every row's reference similarity lies within
+    +-4 ulp of the threshold, on both sides and exactly on it.  Rows are found by a vectorised bisection on the mixing
+    angle between the condition row and an orthogonal direction, evaluated with the SAME torch expressions token_selector
+    uses (utils.py:310-312); the expected outputs come from the reference's token_selector on the assembled tensor."""
+    u = ns.flux_utils
+    Fn = torch.nn.functional.normalize
+    d, idx = {}, 0
+    h = w = 16
+    L = h * w
+    for cond_dtype in (torch.float32, torch.bfloat16):
+        for thr in (0.80, 0.88, 0.93):
+            g = torch.Generator().manual_seed(4000 + idx)
+            R = 20000
+            cond = torch.randn(1, R, 64, generator=g).to(cond_dtype)
+            c64 = cond[0].double()
+            uvec = c64 / c64.norm(dim=-1, keepdim=True)
+            n = torch.randn(R, 64, generator=g, dtype=torch.float64)
+            n = n - (n * uvec).sum(-1, keepdim=True) * uvec
+            vvec = n / n.norm(dim=-1, keepdim=True)
+            mag = torch.rand(R, 1, generator=g, dtype=torch.float64) * 7.5 + 0.5
+
+            def sims(theta):
+                est = ((torch.cos(theta)[:, None] * uvec + torch.sin(theta)[:, None] * vvec) * mag).float()[None]
+                return est, torch.sum(Fn(est, dim=-1) * Fn(cond, dim=-1), dim=-1)[0]
+            th0 = float(np.arccos(thr))
+            lo = torch.full((R,), th0 - 0.02, dtype=torch.float64)      # smaller angle -> larger similarity
+            hi = torch.full((R,), th0 + 0.02, dtype=torch.float64)
+            target = torch.randint(-4, 5, (R,), generator=g)            # wanted offset in ulps of thr
+            thr32 = np.float32(thr)
+            ulp = float(np.spacing(thr32))
+            goal = (torch.full((R,), float(thr32), dtype=torch.float64) + target.double() * ulp)
+            for _ in range(60):
+                mid = (lo + hi) / 2
+                _, s = sims(mid)
+                above = s.double() > goal
+                lo = torch.where(above, mid, lo)
+                hi = torch.where(above, hi, mid)
+            est, s = sims((lo + hi) / 2)
+            off = torch.round((s.double() - float(thr32)) / ulp).long()
+            # stratified pick: as equal a share of every offset in [-4, 4] as the candidates allow
+            pick = []
+            for o in range(-4, 5):
+                cand = torch.nonzero(off == o)[:, 0]
+                pick.append(cand[: (L + 8) // 9 + 2])
+            pick = torch.cat(pick)
+            pick = pick[torch.randperm(pick.numel(), generator=g)][:L]
+            assert pick.numel() == L, (idx, pick.numel())
+            est_c, cond_c = est[:, pick].contiguous(), cond[:, pick].contiguous()
+            sim = torch.sum(Fn(est_c, dim=-1) * Fn(cond_c, dim=-1), dim=-1)
+            offs = torch.round((sim[0].double() - float(thr32)) / ulp).long()
+            assert int(offs.abs().max()) <= 4 and int((offs == 0).sum()) > 0 and int((offs > 0).sum()) > 0
+            raw = (sim <= thr).squeeze(0)
+            for ed in (False, True):
+                e, un = u.token_selector(est_c, cond_c, thr, similarity_type="cosine", height=h * 16, width=w * 16,
+                                         erosion_dilation=ed, patch_size=2, vae_scale_factor=8)
+                final = torch.zeros(L, dtype=torch.uint8)
+                final[e[0]] = 1
+                pair = idx // 2                      # the two erosion settings share one input pair
+                d[f"p{pair}_est"], d[f"p{pair}_cond"] = est_c, cond_c
+                c = dict(h=h, w=w, thr=thr, ed=ed, bf16=int(cond_dtype == torch.bfloat16), pair=pair,
+                         sim=sim.squeeze(0), ulp_offset=offs.to(torch.int8), raw=np.packbits(raw.numpy().astype(np.uint8)),
+                         final=np.packbits(final.numpy()), edited=e.squeeze(0).to(torch.int32),
+                         unedited=un.squeeze(0).to(torch.int32))
+                for k, v in c.items():
+                    d[f"c{idx}_{k}"] = v
+                idx += 1
+            print(f"   arp_adv thr={thr} bf16={cond_dtype == torch.bfloat16}: offsets", np.bincount(offs.numpy() + 4, minlength=9),
+                  " raw ones", int(raw.sum()))
+    d["n"] = idx
+    save("arp_adv", d)
+
+
 def gen_morph(ns):
     u = ns.flux_utils
     torch.manual_seed(7)
@@ -920,6 +993,8 @@ def main():
     which = set(sys.argv[1:]) or {"arp", "morph", "loop", "avd", "toy"}
     if "arp" in which:
         gen_arp(ns)
+    if "arp" in which or "arpadv" in which:
+        gen_arp_adv(ns)
     if "morph" in which:
         gen_morph(ns)
     if "avd" in which:
