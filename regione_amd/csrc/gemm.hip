@@ -20,6 +20,8 @@
 #include "common.h"
 #include <stdlib.h>
 #include <math.h>
+#include <utility>
+#include "gemm_loop_asm.inc"
 
 namespace rgn {
 
@@ -157,14 +159,36 @@ __device__ __forceinline__ void store_nt16(uint16_t* dst, const uint16_t (&v)[8]
 }
 
 
+
+// ---- helpers of the hand-scheduled 4-wave variant (accumulators live in AGPRs a[0:255], tools/gen_gemm_loop.py) ----
+template <int B>
+__device__ __forceinline__ void agpr_read4(float (&c)[4]) {
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(c[0]), "=v"(c[1]), "=v"(c[2]), "=v"(c[3])
+                 : "n"(B), "n"(B + 1), "n"(B + 2), "n"(B + 3));
+}
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_s;
+
 // Tile configurations:
 //   <128,128,2,2>: 4 waves, wave tile 64x64, 64 KiB LDS, 2 blocks/CU  - small / ragged problems
 //   <256,256,2,4>: 8 waves, wave tile 128x64, 128 KiB LDS, 1 block/CU - large problems (half the
 //                  global->LDS traffic and 25 % less LDS read traffic per FLOP)
-template <int EPI, int BM, int BN, int WM, int WN, int MODE>
+//   <256,256,2,2>: 4 waves, wave tile 128x128, accumulators in 256 AGPRs, K loop = ONE hand-scheduled asm statement
+//                  (gemm_loop_asm.inc); MODE_FULL only, K >= 128, operands < 4 GiB
+template <int EPI, int BM, int BN, int WM, int WN, int MODE, int AV = 0>
 __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void gemm_bf16_kernel(const GemmGroup gg) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16x16 MFMA tiles per wave
+    constexpr bool ASM4W = (BM == 256 && BN == 256 && WM == 2 && WN == 2);
+    static_assert(!ASM4W || MODE == MODE_FULL, "the hand-scheduled variant only runs whole-K tiles");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB DMA pieces per wave per stage
     constexpr int CT_LD = BN + 8;                              // padded bf16 row of the C staging tile
@@ -240,10 +264,12 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
     }
 
     f32x4 acc[TM][TN];
+    if constexpr (!ASM4W) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int nk_all = g.K / BK;
     int k_begin = 0, nk = nk_all;
@@ -252,6 +278,61 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
         k_begin = split * per;
         nk = max(0, min(per, nk_all - k_begin));
     }
+    if constexpr (ASM4W) {
+        // ---- hand-scheduled K loop (tools/gen_gemm_loop.py): per-lane SOURCE byte offsets of this wave's 8 + 8 DMA pieces
+        // (same swizzled image as stage()), LDS fragment addresses of stage 0, buffer resources, loop count ----
+        uint32_t oa[PA], ob[PB];
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+            const int ar = min(m0 + (wave * PA + q) * 8 + srow, g.M - 1);
+            oa[q] = (uint32_t)ar * (uint32_t)(g.lda * 2) + schunk * 16;
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int br = min(n0 + (wave * PB + q) * 8 + srow, g.N - 1);
+            ob[q] = (uint32_t)br * (uint32_t)(g.ldw * 2) + schunk * 16;
+        }
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+        uint32_t la0 = lds0 + a_off[0], la1 = lds0 + a_off[1];
+        uint32_t lb0 = lds0 + b_off[0] - A_BYTES, lb1 = lds0 + b_off[1] - A_BYTES;      // the asm adds A_BYTES as an immediate
+        auto rsrc = [](const void* p) {
+            const uint64_t a = (uint64_t)p;
+            u32x4_s r;
+            r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+            r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);      // stride 0: raw buffer
+            r[2] = 0xffffffffu;                                                          // rows are clamped by the offsets
+            r[3] = 0x00020000u;
+            return r;
+        };
+        const u32x4_s pa = rsrc(g.A), pw = rsrc(g.W);
+        uint32_t stg = __builtin_amdgcn_readfirstlane(lds0 + wave * (PA * 1024));
+        uint32_t koff = 0;
+        if constexpr (AV == 0) {
+            uint32_t cnt = __builtin_amdgcn_readfirstlane(nk - 2);
+            asm volatile(RGN_GEMM_LOOP4W_ASM
+                         : [la0] "+&v"(la0), [la1] "+&v"(la1), [lb0] "+&v"(lb0), [lb1] "+&v"(lb1), [cnt] "+&s"(cnt), [stg] "+&s"(stg),
+                           [koff] "+&s"(koff)
+                         : [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
+                           [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ob0] "v"(ob[0]), [ob1] "v"(ob[1]), [ob2] "v"(ob[2]), [ob3] "v"(ob[3]),
+                           [ob4] "v"(ob[4]), [ob5] "v"(ob[5]), [ob6] "v"(ob[6]), [ob7] "v"(ob[7]), [pa] "s"(pa), [pw] "s"(pw)
+                         : RGN_GEMM_LOOP4W_CLOBBERS);
+        } else {
+            // ring variant: A slots at 0 / 32 K, W slots at 64 K / 96 K / 128 K (all 160 KiB), W two tiles ahead
+            uint32_t cnt = __builtin_amdgcn_readfirstlane(nk - 3);
+            const uint32_t lbo0 = lb0 - lds0, lbo1 = lb1 - lds0;
+            const uint32_t wwrap = __builtin_amdgcn_readfirstlane(lds0 + 65536 + wave * (PB * 1024));
+            uint32_t was = wwrap, wrd = __builtin_amdgcn_readfirstlane(lds0 + 65536), kofw = 0;
+            asm volatile(RGN_GEMM_LOOP4W_RING_ASM
+                         : [la0] "+&v"(la0), [la1] "+&v"(la1), [lb0] "=&v"(lb0), [lb1] "=&v"(lb1), [cnt] "+&s"(cnt), [stg] "+&s"(stg),
+                           [koff] "+&s"(koff), [was] "+&s"(was), [wrd] "+&s"(wrd), [kofw] "+&s"(kofw)
+                         : [oa0] "v"(oa[0]), [oa1] "v"(oa[1]), [oa2] "v"(oa[2]), [oa3] "v"(oa[3]), [oa4] "v"(oa[4]), [oa5] "v"(oa[5]),
+                           [oa6] "v"(oa[6]), [oa7] "v"(oa[7]), [ob0] "v"(ob[0]), [ob1] "v"(ob[1]), [ob2] "v"(ob[2]), [ob3] "v"(ob[3]),
+                           [ob4] "v"(ob[4]), [ob5] "v"(ob[5]), [ob6] "v"(ob[6]), [ob7] "v"(ob[7]), [pa] "s"(pa), [pw] "s"(pw),
+                           [lbo0] "v"(lbo0), [lbo1] "v"(lbo1), [wwrap] "s"(wwrap)
+                         : RGN_GEMM_LOOP4W_CLOBBERS);
+        }
+    }
+    if constexpr (!ASM4W) {
     if (MODE != MODE_REDUCE && nk > 0) {
         stage(k_begin, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,6 +357,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
+    }
     }
     if (MODE == MODE_PARTIAL) {
         // lane-linear fp32 fragment dump: [unit][split][fragment (i,j)][thread] float4 - fully coalesced
@@ -348,17 +430,37 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                 // the bf16 cache (fused_kernels.py:80, quirk A-3): K / V columns of a partial-update problem take the same
                 // fp32 -> fp16 -> bf16 double rounding; every other column rounds once, like F.linear
                 const bool f16rt = (EPI == RGN_EPI_QKV) && g.qkv.fp16_roundtrip && n0 < g.qkv.q_col;
+                auto put = [&](int i, float (&c)[4]) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    float c[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) c[r] = acc[i][j][r] + bv[r];
+                    for (int r = 0; r < 4; ++r) c[r] += bv[r];
                     if (f16rt) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) c[r] = (float)(_Float16)c[r];
                     }
                     const uint2 w = make_uint2(cvt_pk_bf16(c[0], c[1]), cvt_pk_bf16(c[2], c[3]));
                     *(uint2*)(ct + (crow0 + i * 16 + mrow) * CT_LD + nl) = w;
+                };
+                if constexpr (ASM4W) {
+                    // j is a runtime index of the (fully unrolled) outer loop: AGPR numbers must be literal -> dispatch
+                    static_for<TN>([&](auto Jc) {
+                        constexpr int J = decltype(Jc)::value;
+                        if (j == J) {
+                            static_for<TM>([&](auto Ic) {
+                                constexpr int I = decltype(Ic)::value;
+                                float c[4];
+                                agpr_read4<(I * TN + J) * 4>(c);
+                                put(I, c);
+                            });
+                        }
+                    });
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float c[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) c[r] = acc[i][j][r];
+                        put(i, c);
+                    }
                 }
             }
         }
@@ -542,31 +644,34 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const uint16_t* __restri
 
 using namespace rgn;
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int AV = 0>
 static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
+    constexpr int LDS = (AV == 1) ? 160 * 1024 : 2 * (BM + BN) * BK * 2;
     constexpr int QKV_TILE = BM * (BN + 8) * 2 + BM * 4;            // whole staged C tile + cache-row table
     constexpr int LDS_QKV = QKV_TILE > LDS ? QKV_TILE : LDS;
     constexpr int NT = 64 * WM * WN;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_QKV, BM, BN, WM, WN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_QKV);
-        attr = true;
+    // the opt-in is per device (one process may drive several GPUs): remember which devices have it
+    static bool attr[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr[dev]) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE, AV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE, AV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE, AV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<RGN_EPI_QKV, BM, BN, WM, WN, MODE, AV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_QKV);
+        if (dev >= 0 && dev < 64) attr[dev] = true;
     }
     const int nb = (MODE == MODE_PARTIAL) ? gg.nt_launch * gg.nsplit : gg.nt_launch;
     if (nb == 0) return 0;
     if (MODE == MODE_PARTIAL) {       // partial fragments carry no epilogue
-        hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg);
+        hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE, AV>), dim3(nb), dim3(NT), LDS, st, gg);
         return check_launch("gemm_bf16_kernel(partial)");
     }
     switch (epilogue) {
-        case RGN_EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
-        case RGN_EPI_GELU: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
-        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS, st, gg); break;
-        case RGN_EPI_QKV: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_QKV, BM, BN, WM, WN, MODE>), dim3(nb), dim3(NT), LDS_QKV, st, gg); break;
+        case RGN_EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_BIAS, BM, BN, WM, WN, MODE, AV>), dim3(nb), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_GELU: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GELU, BM, BN, WM, WN, MODE, AV>), dim3(nb), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_GATE_RESID: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_GATE_RESID, BM, BN, WM, WN, MODE, AV>), dim3(nb), dim3(NT), LDS, st, gg); break;
+        case RGN_EPI_QKV: hipLaunchKernelGGL((gemm_bf16_kernel<RGN_EPI_QKV, BM, BN, WM, WN, MODE, AV>), dim3(nb), dim3(NT), LDS_QKV, st, gg); break;
         default: return fail(RGN_E_BADARG, "gemm: unknown epilogue");
     }
     return check_launch("gemm_bf16_kernel");
@@ -652,8 +757,20 @@ static float estimate128(int nt, int K, double flops) {
     return fmaxf(t, (float)(flops / 1.05e15 * 1e6));
 }
 
+// whole-K launches of the 256x256 configuration: the hand-scheduled 4-wave kernel where it applies
 template <int BM, int BN, int WM, int WN>
-static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, void* ws, hipStream_t st) {
+static int launch_full(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_t st) {
+    if constexpr (BM == 256 && BN == 256) {
+        // RGN_GEMM_ASMV: 0 = two 64 KiB stages, 1 = A ring of two + W ring of three 32 KiB slots (needs >= 4 K tiles)
+        static const int asmv = [] { const char* e = getenv("RGN_GEMM_ASMV"); return e ? atoi(e) : 1; }();
+        if (asm4w && asmv == 1 && gg.p[0].K >= 4 * BK) return launch_gemm<256, 256, 2, 2, MODE_FULL, 1>(gg, epilogue, st);
+        if (asm4w) return launch_gemm<256, 256, 2, 2, MODE_FULL, 0>(gg, epilogue, st);
+    }
+    return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, void* ws, hipStream_t st, bool asm4w = false) {
     const int nt = gg.nt;
     const int full = (nt / slots) * slots, left = nt - full;
     const char* v = getenv("RGN_GEMM_SPLIT");
@@ -663,11 +780,11 @@ static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, voi
     int rc;
     if (nsplit == 1) {
         gg.tile_offset = 0; gg.nt_launch = nt;
-        return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
+        return launch_full<BM, BN, WM, WN>(gg, epilogue, asm4w, st);
     }
     if (full > 0) {
         gg.tile_offset = 0; gg.nt_launch = full;
-        if ((rc = launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st))) return rc;
+        if ((rc = launch_full<BM, BN, WM, WN>(gg, epilogue, asm4w, st))) return rc;
     }
     gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = nsplit;
     if ((rc = launch_gemm<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, st))) return rc;
@@ -689,12 +806,18 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
     bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < 0.92f * e128);
     const char* v = getenv("RGN_GEMM_VARIANT");
     if (v && v[0] == '1') use_big = false;
-    if (v && v[0] == '2') use_big = true;
+    if (v && (v[0] == '2' || v[0] == '3')) use_big = true;
+    // hand-scheduled 4-wave K loop for the whole-K tiles: needs >= 2 K tiles and 32-bit operand offsets
+    bool asm4w = K >= 2 * BK;
+    for (int i = 0; i < nprob; ++i)
+        asm4w = asm4w && (size_t)gg.p[i].M * gg.p[i].lda * 2 < ((size_t)1 << 32) && (size_t)gg.p[i].N * gg.p[i].ldw * 2 < ((size_t)1 << 32);
+    static const int asm_default = [] { const char* e = getenv("RGN_GEMM_ASM"); return e ? atoi(e) : 1; }();   // RGN_GEMM_ASM=0: A/B switch
+    if (!(asm_default || (v && v[0] == '3')) || (v && v[0] == '2')) asm4w = false;
     const int b = use_big ? 256 : 128;
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
     if (gg.nt == 0) return 0;
-    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, p256.nsplit, ws, st)
+    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, p256.nsplit, ws, st, asm4w)
                    : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, split128(gg.nt, K, ws != nullptr, ws_bytes), ws, st);
 }
 

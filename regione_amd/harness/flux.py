@@ -8,7 +8,11 @@ names and call signatures:
     pipeline.scheduler            FlowMatchEulerDiscreteScheduler.step
     pipeline.transformer.forward  FluxTransformer2DModel.forward
     block.attn.set_processor(p)   p(attn, hidden_states, encoder_hidden_states=None,
-                                    attention_mask=None, image_rotary_emb=None)
+                                    attention_mask=None, image_rotary_emb=None[, tag=None])
+                                  (exactly the reference's processor signatures, inplace.py:704-711,
+                                  Step1XEditV1P2/inplace.py:806-814, QwenImageEdit/inplace.py:737-746; the engine's
+                                  per-forward context travels ON the attention module - `attn.fwd_ctx`, `attn.block` -
+                                  like the projection weights the reference's processors read off `attn`)
 
 Everything below [EXT] restates upstream diffusers semantics (the reference only *calls* them) on
 top of regione_amd.ops; the MMDiT arithmetic itself runs in libregione_hip.so.  There is no torch
@@ -204,16 +208,21 @@ SKIP_UNREAD_ROWS = os.environ.get("RGN_SKIP_UNREAD_ROWS", "1") != "0"
 
 
 class Attention:
-    """Weight container + processor slot (diffusers.models.attention_processor.Attention)."""
+    """Weight container + processor slot (diffusers.models.attention_processor.Attention).  Besides the weights the
+    module carries the engine state of the forward in flight (`fwd_ctx`: workspace, lengths, modulation table, CFG tag;
+    `block`: the owning block) - set by the block right before it calls the module, read by the processor."""
 
     def __init__(self, heads: int, head_dim: int):
         self.heads, self.head_dim = heads, head_dim
         self.processor = None
+        self.fwd_ctx: Optional["FwdCtx"] = None
+        self.block = None
 
     def set_processor(self, processor):
         self.processor = processor
 
     def __call__(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+        # diffusers' Attention.forward: unknown cross-attention kwargs are dropped unless the processor's __call__ names them
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
                               attention_mask=attention_mask, **kw)
 
@@ -231,7 +240,10 @@ class FluxAttnProcessor:
         return ws.k_scratch, ws.vt_scratch, None, ctx.T + ctx.M, None
 
     def __call__(self, attn: Attention, hidden_states, encoder_hidden_states=None, attention_mask=None,
-                 image_rotary_emb=None, ctx: FwdCtx = None, block=None):
+                 image_rotary_emb=None, tag=None, encoder_hidden_states_mask=None):
+        ctx, block = attn.fwd_ctx, attn.block
+        if tag is not None:
+            ctx.tag = tag
         ws, T, M, d, H = ctx.ws, ctx.T, ctx.M, attn.heads * attn.head_dim, attn.heads
         R = T + M
         wide = ws.wide[:R]
@@ -325,8 +337,8 @@ class FluxTransformerBlock:
         # norm1 / norm1_context: LN * (1 + scale_msa) + shift_msa   (chunks: shift, scale, gate, shift, scale, gate)
         ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo_img, 0), mods.chunk(self.mo_img, 1), split_row=T,
                         shift0=mods.chunk(self.mo_ctx, 0), scale0=mods.chunk(self.mo_ctx, 1))
-        self.attn(hidden_states=ws.nrm[T:R], encoder_hidden_states=ws.nrm[:T], image_rotary_emb=image_rotary_emb,
-                  ctx=ctx, block=self)
+        self.attn.fwd_ctx, self.attn.block = ctx, self
+        self.attn(hidden_states=ws.nrm[T:R], encoder_hidden_states=ws.nrm[:T], image_rotary_emb=image_rotary_emb)
         if getattr(self, "is_last", False) and ctx.out_rows is not None and not getattr(ctx, "partial_kv", False):
             lo, hi = T, T + ctx.out_rows                      # only these rows of the trunk's output are read
             ops.ln_modulate(ws.x[lo:hi], ws.nrm[lo:hi], mods.chunk(self.mo_img, 3), mods.chunk(self.mo_img, 4))
@@ -361,7 +373,8 @@ class FluxSingleTransformerBlock:
         ws, T, M, mods = ctx.ws, ctx.T, ctx.M, ctx.mods
         R = T + M
         ops.ln_modulate(ws.x[:R], ws.nrm[:R], mods.chunk(self.mo, 0), mods.chunk(self.mo, 1))
-        cat = self.attn(hidden_states=ws.nrm[:R], image_rotary_emb=image_rotary_emb, ctx=ctx, block=self)
+        self.attn.fwd_ctx, self.attn.block = ctx, self
+        cat = self.attn(hidden_states=ws.nrm[:R], image_rotary_emb=image_rotary_emb)
         rows = ws.x[:R] if cat.shape[0] == R else ws.x[T:T + cat.shape[0]]      # last block: only the rows the caller reads
         ops.gemm(cat, self.w_po, self.b_po, rows, epilogue=ops.EPI_GATE_RESID, gate=mods.chunk(self.mo, 2), resid=rows)
         return ws.x[:T], ws.x[T:R]

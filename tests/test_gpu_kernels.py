@@ -21,12 +21,14 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 256, 192), (1, 128, 64), (1000, 64, 3072),
                                    (777, 200, 128), (8704, 3072, 3072)])
 def test_gemm_bias(M, N, K, variant, monkeypatch):
     from regione_amd import ops
-    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)          # 1 = 128x128 tiles, 2 = 256x256 tiles
+    # 1 = 128x128 tiles, 2 = 256x256 tiles (8 waves, hipcc-scheduled loop), 3 = 256x256 tiles with the hand-scheduled
+    # 4-wave K loop wherever it applies (K >= 128)
+    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
     g = torch.Generator().manual_seed(M * 7 + N)
     # asymmetric operands so a transposed C-write cannot pass (guide rule 16)
     A = bf(torch.randn(M, K, generator=g))
@@ -81,7 +83,7 @@ def test_gemm_strided_views_scatter_and_epilogues():
     assert rel_err(cache.cpu()[idx], ref[idx]) < 3e-3
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 def test_gemm_pair_two_problems_one_launch(variant, monkeypatch):
     from regione_amd import ops
     monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
@@ -293,7 +295,7 @@ def _qkv_case(M, H, K, mlp, gen, kv_rows=None, skv=None, row_base=0):
     return A, W, b, wq, wk, (cos, sin), D, N, skv
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
 @pytest.mark.parametrize("M,H,K,mlp,gather,row_base", [(600, 2, 256, 1024, False, 0), (333, 2, 256, 0, True, 0),
                                                        (512, 4, 512, 2048, False, 16), (200, 2, 256, 0, True, 24)])
 def test_gemm_qkv_fused_epilogue_bit_identical_to_separate_kernels(M, H, K, mlp, gather, row_base, variant, monkeypatch):
@@ -393,3 +395,44 @@ def test_gemm_qkv_fp16_roundtrip_option():
     dv = (v0.float() - v1.float()).abs()
     assert float((v0 != v1).float().mean()) > 0.0 and float((dv / v0.float().abs().clamp_min(1e-3)).max()) <= 2 ** -7
     assert float((k0.float() - k1.float()).abs().max()) <= 2 ** -5 * float(k0.float().abs().max())
+
+
+@pytest.mark.parametrize("asmv", ["0", "1"])
+@pytest.mark.parametrize("M,N,K,epi", [(8704, 3072, 3072, "bias"), (1536, 21504, 3072, "gelu"), (700, 3072, 15360, "gate"),
+                                       (513, 520, 128, "bias"), (8192, 512, 192, "gelu"), (300, 704, 256, "gate"),
+                                       (2000, 1000, 320, "bias")])
+def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, epi, asmv, monkeypatch):
+    """The 4-wave asm K loop (variant 3) accumulates every output element over k in the same MFMA order as the 8-wave
+    kernel (variant 2): results must be bit-identical, for every epilogue, ragged edges included.  asmv 0 = two 64 KiB
+    stages, 1 = A ring of two / W ring of three 32 KiB slots (K >= 256; shorter K falls back to asmv 0)."""
+    from regione_amd import ops
+    import subprocess, sys, os
+    if asmv == "1":
+        # RGN_GEMM_ASMV is read once per process: run this case in a child
+        env = dict(os.environ, RGN_GEMM_ASMV="1", PYTEST_ASMV_CHILD="1")
+        if os.environ.get("PYTEST_ASMV_CHILD") != "1":
+            r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k",
+                                f"test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled and {M}-{N}-{K}-{epi}-1"],
+                               env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+            assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+            return
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).cuda()
+    W = bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+    b = bf(torch.randn(N, generator=g)).cuda()
+    gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
+    outs = []
+    for variant in ("2", "3"):
+        monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+        if epi == "gate":
+            o = x.clone()
+            ops.gemm(A, W, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
+        else:
+            o = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(A, W, b, o, epilogue=ops.EPI_GELU if epi == "gelu" else ops.EPI_BIAS, gelu_from_col=N // 2 // 8 * 8)
+        outs.append(o)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    ref = F.linear(A.float(), W.float(), b.float())
+    if epi == "bias":
+        assert rel_err(outs[1].cpu(), ref.cpu()) < 3e-3

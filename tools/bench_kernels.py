@@ -40,14 +40,25 @@ def bench_gemm():
     if os.environ.get("GEMM_KSWEEP"):      # 1024 tiles = 4 exact rounds: per-tile time = a*K + b separates loop rate from tile overhead
         shapes = [(f"ksweep {k}", 8192, 8192, k) for k in (512, 1024, 2048, 3072, 4096, 8192)]
     only = os.environ.get("GEMM_ONLY")
+    # GEMM_COLD=1: every launch reads a DIFFERENT copy of W (enough copies to overflow the 256 MiB Infinity Cache), like
+    # the pipeline, where each layer's weights arrive from HBM; without it 25 back-to-back launches re-read W from the MALL
+    cold = os.environ.get("GEMM_COLD")
     for name, M, N, K in shapes:
         if only and only not in name:
             continue
         A, W, b = rnd(M, K), rnd(N, K) * 0.05, rnd(N)
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        Ws = [W]
+        if cold:
+            Ws += [W.clone() for _ in range(max(1, int(600e6 // (N * K * 2))))]
+        state = {"i": 0}
+
+        def run():
+            state["i"] = (state["i"] + 1) % len(Ws)
+            ops.gemm(A, Ws[state["i"]], b, out)
         for variant in VARIANTS:
             os.environ["RGN_GEMM_VARIANT"] = variant
-            med, best = timeit(lambda: ops.gemm(A, W, b, out))
+            med, best = timeit(run)
             fl = 2.0 * M * N * K
             print(f"gemm[{variant:>4}] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
         if os.environ.get("GEMM_VENDOR"):      # reference point only: the vendor library (hipBLASLt via torch), bias epilogue

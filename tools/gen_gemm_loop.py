@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate the hand-scheduled K loop of the 256x256x64 bf16 GEMM (regione_amd/csrc/gemm_loop_asm.inc).
+
+    python tools/gen_gemm_loop.py            # rewrites the .inc (committed; the build does not run this script)
+
+Why a generator: the loop is ONE inline-asm statement per variant - hipcc schedules `ds_read`, LDS-DMA and MFMA
+its own way (every 8 MFMAs it waits lgkmcnt(0) in front of two fresh fragment reads, drains vmcnt(0) in front of the
+tile barrier) and cannot be talked out of it.  Here every instruction slot is placed by hand:
+
+  * 4 waves (2 x 2), wave tile 128 x 128 = 8 x 8 `v_mfma_f32_16x16x32_bf16`, 256 accumulator registers in AGPRs
+    a[0:255]; fragment registers v[128:255] = two sets (one per 32-deep k-half), so the fragments of the NEXT k-half are
+    always in flight behind the MFMAs of the current one (no exposed LDS latency);
+  * two 64 KiB LDS stages ([A 256 rows][B 256 rows] x 128-byte rows, 16-byte slot ^= row & 7 - the same image
+    gemm_bf16_kernel builds); ONE barrier per K tile, placed in the MIDDLE of the tile: when a wave arrives its second
+    fragment set is already loaded, so it leaves the barrier with 64 MFMAs of work in hand; behind the barrier the
+    stage just read is free and the wave's 16 LDS-DMA pieces of tile t+2 are issued one per 4 MFMAs;
+  * counted waits only: lgkmcnt(0) falls 32+ MFMAs after the last read was issued, vmcnt(0) a full tile after the
+    last piece was issued.
+
+Register plan (per wave):  a[(i*TN + j)*4 + r]  accumulator (i = A fragment, j = W fragment, r = column in the lane's 4)
+                           v[128 + 64*set + 4*f]  fragment f of set (f < 8: A rows, f >= 8: W rows)
+Named operands (bound in gemm.hip): oa0..oa7 / ob0..ob7 per-lane source byte offsets of the A / W pieces, la0 / la1 LDS read
+address of the A fragments (k-half 0 / 1), lb0 / lb1 of the W fragments, pa / pw buffer resources of A / W (4 SGPRs each),
+cnt loop count (nk - 2), stg LDS base of this wave's DMA slots in the stage refilled next, koff byte offset of the current
+K tile (the buffer instruction's scalar offset: ONE s_add per tile advances both operands).
+"""
+import os
+
+TM = TN = 8
+FRAG0 = 128                     # first fragment VGPR
+A_BYTES = 256 * 128             # A region of a stage
+STAGE = 2 * A_BYTES
+# named asm operands (gemm.hip binds them)
+PA, PW, CNT, STG, KOFF = "[pa]", "[pw]", "[cnt]", "[stg]", "[koff]"
+
+
+def OA(q):
+    return f"[oa{q}]"
+
+
+def OB(q):
+    return f"[ob{q}]"
+
+
+def LA(kh):
+    return f"[la{kh}]"
+
+
+def LB(kh):
+    return f"[lb{kh}]"
+
+
+def frag(set_, f):
+    b = FRAG0 + 64 * set_ + 4 * f
+    return f"v[{b}:{b + 3}]"
+
+
+def acc(i, j):
+    b = (i * TN + j) * 4
+    return f"a[{b}:{b + 3}]"
+
+
+def mfma(set_, k):
+    i, j = divmod(k, TN)
+    return f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {frag(set_, 8 + j)}, {frag(set_, i)}, {acc(i, j)}"
+
+
+def zero_acc():
+    return [f"v_accvgpr_write_b32 a{n}, 0" for n in range(TM * TN * 4)]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# variant 0: two 64 KiB stages [A | W]; every operand has ONE tile of lead
+# ------------------------------------------------------------------------------------------------------------------
+def reads(set_, khalf):
+    """16 fragment reads of one k-half into fragment set `set_` (A and W alternating, in the order the MFMAs need them)."""
+    out = []
+    for f in range(8):
+        out.append(f"ds_read_b128 {frag(set_, f)}, %{LA(khalf)} offset:{f * 2048}")
+        out.append(f"ds_read_b128 {frag(set_, 8 + f)}, %{LB(khalf)} offset:{A_BYTES + f * 2048}")
+    return out
+
+
+def dma_pieces():
+    """(m0 setup, DMA) pairs of the 16 pieces one wave stages per tile."""
+    out = []
+    for q in range(8):
+        out.append((f"s_add_u32 m0, %{STG}, {q * 1024}", f"buffer_load_dwordx4 %{OA(q)}, %{PA}, %{KOFF} offen lds"))
+    for q in range(8):
+        out.append((f"s_add_u32 m0, %{STG}, {A_BYTES + q * 1024}", f"buffer_load_dwordx4 %{OB(q)}, %{PW}, %{KOFF} offen lds"))
+    return out
+
+
+def advance():
+    return [f"s_add_u32 %{KOFF}, %{KOFF}, 128", f"s_xor_b32 %{STG}, %{STG}, 0x10000"]
+
+
+def prologue():
+    ins = []
+    for _tile in range(2):
+        for m0set, ld in dma_pieces():
+            ins += [m0set, "s_nop 0", ld]
+        ins += advance()
+    ins += zero_acc()                  # accumulators cleared while the first tiles are in flight
+    ins += ["s_waitcnt vmcnt(16)", "s_barrier"]
+    ins += reads(0, 0)
+    ins += ["s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+def body(dma, nxt):
+    """One K tile: phase 1 = k-half 0 (fragment set 0), phase 2 = k-half 1 (set 1)."""
+    ins = []
+    r1 = reads(1, 1)
+    for k in range(64):
+        ins.append(mfma(0, k))
+        if k % 2 == 1 and r1:
+            ins.append(r1.pop(0))
+    assert not r1
+    ins.append("s_waitcnt lgkmcnt(0)")
+    if nxt:
+        ins += ["s_waitcnt vmcnt(0)", "s_barrier"]
+        for o in (LA(0), LA(1), LB(0), LB(1)):
+            ins.append(f"v_xor_b32 %{o}, 0x10000, %{o}")
+    else:
+        ins.append("s_barrier")                    # last tile: every wave is done with the stages -> the epilogue may reuse LDS
+    r0 = reads(0, 0) if nxt else []
+    pcs = dma_pieces() if dma else []
+    adv = advance() if dma else []
+    for k in range(64):
+        ins.append(mfma(1, k))
+        g = k % 4
+        if g == 0 and pcs:
+            ins.append(pcs[0][0])                 # m0 of the piece issued behind the next MFMA
+        elif g == 1 and pcs:
+            ins.append(pcs.pop(0)[1])
+        elif g == 2 and r0:
+            ins.append(r0.pop(0))
+        elif g == 3 and r0:
+            ins.append(r0.pop(0))
+        if not pcs and adv and g == 1:
+            ins.append(adv.pop(0))
+    ins += adv
+    assert not r0 and not pcs
+    if nxt:
+        ins.append("s_waitcnt lgkmcnt(0)")
+    return ins
+
+
+def emit_v0():
+    lines = []
+    lines += prologue()
+    lines += [f"s_cmp_eq_u32 %{CNT}, 0", "s_cbranch_scc1 2f", "1:"]
+    lines += body(True, True)
+    lines += [f"s_sub_u32 %{CNT}, %{CNT}, 1", f"s_cmp_lg_u32 %{CNT}, 0", "s_cbranch_scc1 1b", "2:"]
+    lines += body(False, True)
+    lines += body(False, False)
+    lines += ["s_nop 15", "s_nop 15"]
+    return lines
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# variant 1: all 160 KiB of LDS - A ring of TWO 32 KiB slots (0, 32 K), W ring of THREE (64 K, 96 K, 128 K).  The weight
+# operand is the HBM-cold one (every W panel is read by one or two XCDs, straight from HBM; the activations were just
+# written by the previous kernel and sit in L2 / Infinity Cache), so W gets TWO tiles of lead, A one.  In the middle of
+# tile t (behind the barrier) the wave issues A(t+2) into the A slot just freed and W(t+3) into the W slot just freed; the
+# wait in front of the barrier is `vmcnt(8)`: everything but the 8 pieces of W(t+2) must have landed.
+# extra operands: was (sgpr) LDS base of the W slot refilled next (this wave's pieces), wrd (sgpr) LDS base of the W slot
+# read next, lbo0 / lbo1 (vgpr) offsets of the W fragments inside a slot; stg = the wave's pieces in the A slot refilled next
+# ------------------------------------------------------------------------------------------------------------------
+WAS, WRD, KOFW = "[was]", "[wrd]", "[kofw]"
+W_SLOT0, W_END, SLOT = 65536, 163840, 32768
+
+
+def LBO(kh):
+    return f"[lbo{kh}]"
+
+
+def reads1(set_, khalf):
+    out = []
+    for f in range(8):
+        out.append(f"ds_read_b128 {frag(set_, f)}, %{LA(khalf)} offset:{f * 2048}")
+        out.append(f"ds_read_b128 {frag(set_, 8 + f)}, %{LB(khalf)} offset:{f * 2048}")
+    return out
+
+
+def dma_a():
+    return [(f"s_add_u32 m0, %{STG}, {q * 1024}", f"buffer_load_dwordx4 %{OA(q)}, %{PA}, %{KOFF} offen lds") for q in range(8)]
+
+
+def dma_w():
+    return [(f"s_add_u32 m0, %{WAS}, {q * 1024}", f"buffer_load_dwordx4 %{OB(q)}, %{PW}, %{KOFW} offen lds") for q in range(8)]
+
+
+def rot(reg):
+    """advance an LDS W-slot base by one slot, wrapping after the third"""
+    return [f"s_add_u32 %{reg}, %{reg}, {SLOT}", f"s_cmp_lt_u32 %{reg}, {W_END}", f"s_cselect_b32 %{reg}, %{reg}, %[wwrap]"]
+
+
+def rot_was():
+    # the wrap target of `was` is slot 0 + this wave's piece offset = %[wwrap]; `wrd` wraps to W_SLOT0 (no wave offset)
+    return [f"s_add_u32 %{WAS}, %{WAS}, {SLOT}", f"s_cmp_lt_u32 %{WAS}, {W_END}", f"s_cselect_b32 %{WAS}, %{WAS}, %[wwrap]"]
+
+
+def rot_wrd():
+    return [f"s_add_u32 %{WRD}, %{WRD}, {SLOT}", f"s_cmp_lt_u32 %{WRD}, {W_END}", f"s_cselect_b32 %{WRD}, %{WRD}, {W_SLOT0}"]
+
+
+def adv_a():
+    return [f"s_add_u32 %{KOFF}, %{KOFF}, 128", f"s_xor_b32 %{STG}, %{STG}, 0x8000"]
+
+
+def adv_w():
+    return [f"s_add_u32 %{KOFW}, %{KOFW}, 128"] + rot_was()
+
+
+def prologue1():
+    ins = []
+
+    def issue(pcs):
+        for m0set, ld in pcs:
+            ins.extend([m0set, "s_nop 0", ld])
+    issue(dma_a()); ins.extend(adv_a())          # A(0)
+    issue(dma_w()); ins.extend(adv_w())          # W(0)
+    issue(dma_a()); ins.extend(adv_a())          # A(1)
+    issue(dma_w()); ins.extend(adv_w())          # W(1)
+    issue(dma_w()); ins.extend(adv_w())          # W(2)
+    ins += zero_acc()
+    ins += ["s_waitcnt vmcnt(24)", "s_barrier"]
+    ins += [f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
+    ins += reads1(0, 0)
+    ins += ["s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+def body1(dmaa, dmaw, nxt, wait):
+    ins = []
+    r1 = reads1(1, 1)
+    for k in range(64):
+        ins.append(mfma(0, k))
+        if k % 2 == 1 and r1:
+            ins.append(r1.pop(0))
+    ins.append("s_waitcnt lgkmcnt(0)")
+    if nxt:
+        ins += [f"s_waitcnt vmcnt({wait})", "s_barrier"]
+        ins += rot_wrd()
+        ins += [f"v_xor_b32 %{LA(0)}, 0x8000, %{LA(0)}", f"v_xor_b32 %{LA(1)}, 0x8000, %{LA(1)}",
+                f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
+    else:
+        ins.append("s_barrier")
+    r0 = reads1(0, 0) if nxt else []
+    pcs = (dma_a() if dmaa else []) + (dma_w() if dmaw else [])
+    adv = (adv_a() if dmaa else []) + (adv_w() if dmaw else [])
+    for k in range(64):
+        ins.append(mfma(1, k))
+        g = k % 4
+        if g == 0 and pcs:
+            ins.append(pcs[0][0])
+        elif g == 1 and pcs:
+            ins.append(pcs.pop(0)[1])
+        elif g == 2 and r0:
+            ins.append(r0.pop(0))
+        elif g == 3 and r0:
+            ins.append(r0.pop(0))
+    ins += adv
+    assert not r0 and not pcs
+    if nxt:
+        ins.append("s_waitcnt lgkmcnt(0)")
+    return ins
+
+
+def emit_v1():
+    """cnt = nk - 3 full bodies (t = 0 .. nk-4), then t = nk-3 (A only), nk-2 (no DMA), nk-1 (last).  Needs nk >= 4."""
+    lines = prologue1()
+    lines += ["1:"]
+    lines += body1(True, True, True, 8)
+    lines += [f"s_sub_u32 %{CNT}, %{CNT}, 1", f"s_cmp_lg_u32 %{CNT}, 0", "s_cbranch_scc1 1b"]
+    lines += body1(True, False, True, 8)
+    lines += body1(False, False, True, 0)
+    lines += body1(False, False, False, 0)
+    lines += ["s_nop 15", "s_nop 15"]
+    return lines
+
+
+def write_macro(f, name, lines):
+    n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+    f.write(f"// {name}: {len(lines)} instructions, {n_mfma} MFMAs\n")
+    f.write(f"#define {name} \\\n")
+    for l in lines:
+        f.write(f'    "{l}\\n\\t" \\\n')
+    f.write('    ""\n')
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "..", "regione_amd", "csrc", "gemm_loop_asm.inc")
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen_gemm_loop.py - do not edit.  Hand-scheduled K loops of gemm_bf16_kernel<.., 256, 256, 2, 2, ..>.\n")
+        write_macro(f, "RGN_GEMM_LOOP4W_ASM", emit_v0())
+        write_macro(f, "RGN_GEMM_LOOP4W_RING_ASM", emit_v1())
+        clob = [f'"a{n}"' for n in range(256)] + [f'"v{n}"' for n in range(FRAG0, 256)] + ['"memory"', '"scc"']
+        f.write("#define RGN_GEMM_LOOP4W_CLOBBERS " + ", ".join(clob) + "\n")
+    print(f"wrote {os.path.normpath(out)}")
+
+
+if __name__ == "__main__":
+    main()
