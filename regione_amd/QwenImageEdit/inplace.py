@@ -69,14 +69,24 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, negative_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, true_cfg_scale=4.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True, trace: Optional[dict] = None):
+                 return_dict=True, trace: Optional[dict] = None, cond_shapes=None):
         MANAGER = self._regione_manager
         assert num_inference_steps == MANAGER.inference_step, "num_inference_steps should be equal to 28"
-        latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps)
+        latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps,
+                                                               cond_shapes)
         timesteps = self.scheduler.timesteps
-        img_shapes = self._shapes(height, width)
+        img_shapes = self._shapes(height, width, cond_shapes)
         do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None           # :238
-        MANAGER.refresh(latents, image_latents, latent_ids, 2, self.vae_scale_factor, height, width)
+        # The partition compares the one-step estimate with the condition latent token by token (utils.py:310-312), which
+        # needs L_c == L.  With several condition images (2509) the reference's own call breaks there (shape mismatch);
+        # here the LAST image - the one that fixes the output size, QwenImageEditPlus/inplace.py:190 - is the reference
+        # image of the partition, and every image stays in the K/V cache.
+        arp_cond = image_latents
+        if image_latents.shape[1] != latents.shape[1]:
+            arp_cond = image_latents[:, image_latents.shape[1] - latents.shape[1]:]
+            assert cond_shapes is not None and int(cond_shapes[-1][0]) * int(cond_shapes[-1][1]) == latents.shape[1], \
+                "the last condition image must have the output token grid"
+        MANAGER.refresh(latents, arp_cond, latent_ids, 2, self.vae_scale_factor, height, width)
         MANAGER.txt_length = prompt_embeds.shape[1]
         avd, cache = fk.AvdState(), None
         self.scheduler.set_begin_index(0)

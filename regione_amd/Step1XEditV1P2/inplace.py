@@ -129,5 +129,5 @@ def RegionEStep1XEditTransformer2DModelforward(self, hidden_states, encoder_hidd
     MANAGER = self._regione_manager
     image_rotary_emb = fk.dual_rope_tables(self, MANAGER, txt_ids, img_ids)
     tag = (joint_attention_kwargs or {}).get("tag", "cond")
-    return self._run(hidden_states, encoder_hidden_states, self._vec[tag], timestep, None, image_rotary_emb, return_dict,
-                     {"tag": tag})
+    enc, y = self.branch_inputs(encoder_hidden_states, self._vec[tag], timestep, tag)      # :602-609 (host connector, if any)
+    return self._run(hidden_states, enc, y, timestep, None, image_rotary_emb, return_dict, {"tag": tag})

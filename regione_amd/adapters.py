@@ -1,9 +1,14 @@
-"""Host-pipeline adapter: put a stock diffusers editing pipeline on the HIP engine.
+"""Host-pipeline adapter: a STOCK diffusers editing pipeline on the HIP engine, with the
+reference's call shape (RegionE/README.md:85-113):
 
-    engine = adopt_engine(pipe)                 # FluxKontext / Step1XEdit(V1P2) / QwenImageEdit(Plus)Pipeline
-    hosted = adopt(pipe)                        # FluxKontextPipeline: image + prompt in, image out
-    helper = RegionEHelper(hosted); helper.set_params(...); helper.enable()
-    image = hosted(image=pil_image, prompt="...", guidance_scale=2.5).images[0]
+    helper = RegionEHelper(pipe)                # FluxKontext / Step1XEdit(V1P2) / QwenImageEdit(Plus)Pipeline object
+    helper.set_params(...); helper.enable()     # adopts the transformer weights once, patches the engine, swaps pipe.__class__
+    image = pipe(image=pil_image, prompt="...").images[0]        # the user keeps calling the pipeline itself
+    helper.disable()                            # pipe is the stock pipeline again
+
+Lower levels, for callers that want them:
+    engine = adopt_engine(pipe)                 # latent-level HIP pipeline of the host's family (weights adopted)
+    hosted = adopt(pipe)                        # wrapper object: hosted(image=..., prompt=...) without touching pipe.__class__
 
 `adopt_engine` reads the host transformer's `state_dict()` (tensor by tensor, straight to the GPU in bf16), infers the
 trunk dimensions from the tensor shapes, maps the family's parameter names onto the engine's FLUX-layout names and
@@ -125,105 +130,384 @@ def adopt_engine(pipe, device="cuda", family: Optional[str] = None, ignore_prefi
         engine_cls = HQ.QwenImageEditPlusPipeline if "Plus" in name else HQ.QwenImageEditPipeline
     tr.load_state_dict_stream((k, v) for k, v in _stream(sd, family, device) if k in want)
     sched_cfg = dict(getattr(pipe.scheduler, "config", {}) or {}) if getattr(pipe, "scheduler", None) is not None else {}
-    known = {k: sched_cfg[k] for k in ("num_train_timesteps", "shift", "use_dynamic_shifting", "base_shift", "max_shift",
-                                       "base_image_seq_len", "max_image_seq_len") if k in sched_cfg}
-    engine = engine_cls(tr, HF.FlowMatchEulerDiscreteScheduler(**known))
+    # every key travels: the engine's scheduler implements shift_terminal / time_shift_type / invert_sigmas and REFUSES
+    # what it does not implement (karras / exponential / beta sigmas, stochastic sampling, unknown keys)
+    engine = engine_cls(tr, HF.FlowMatchEulerDiscreteScheduler(**sched_cfg))
     if hasattr(pipe, "vae_scale_factor"):
         engine.vae_scale_factor = pipe.vae_scale_factor
     return engine
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# hosted calls: everything OUTSIDE the denoise loop on the host pipeline's own methods, the loop on the engine
+# ---------------------------------------------------------------------------------------------------------------------
+# Kontext's training resolutions (diffusers FluxKontextPipeline; reference copy RegionE/FluxKontext/utils.py:18-36):
+# the default target of `_auto_resize`
+PREFERRED_KONTEXT_RESOLUTIONS = [(672, 1568), (688, 1504), (720, 1456), (752, 1392), (800, 1328), (832, 1248), (880, 1184),
+                                 (944, 1104), (1024, 1024), (1104, 944), (1184, 880), (1248, 832), (1328, 800), (1392, 752),
+                                 (1456, 720), (1504, 688), (1568, 672)]
+STEP1X_DEFAULT_NEGATIVE = ("worst quality, wrong limbs, unreasonable limbs, normal quality, low quality, low res, blurry, text, "
+                           "watermark, logo, banner, extra digits, cropped, jpeg artifacts, signature, username, error, sketch ,"
+                           "duplicate, ugly, monochrome, horror, geometry, mutation, disgusting")    # Step1XEdit/inplace.py:231
+QWEN_CONDITION_IMAGE_SIZE, QWEN_VAE_IMAGE_SIZE = 384 * 384, 1024 * 1024                                # QwenImageEditPlus/inplace.py:53-54
+
+
 class HostedOutput(dict):
-    def __init__(self, images):
+    def __init__(self, images, timing=None):
         super().__init__(images=images)
         self.images = images
+        self.timing = timing or {}           # wall-clock seconds of the three stages: encode / loop / decode
 
 
-class HostedFluxKontextPipeline:
-    """Host pipeline for everything outside the loop, HIP engine for the loop.  RegionEHelper(hosted) patches the engine."""
+def _bf(t, dev):
+    return t.to(device=dev, dtype=torch.bfloat16) if t is not None else None
+
+
+def _one_image_only(prompt, num_images_per_prompt):
+    if num_images_per_prompt != 1 or (isinstance(prompt, list) and len(prompt) != 1):
+        raise ValueError("the region-aware loop is batch-1 (token_selector squeezes the batch, utils.py:337-343): "
+                         "one image per call, shard images across GPUs")
+
+
+class _Clock:
+    """Wall-clock of the stages of an edit (end-to-end = encode + loop + decode)."""
+
+    def __init__(self, dev):
+        import time
+        self.dev, self.t, self.time, self.out = dev, None, time, {}
+        self.mark(None)
+
+    def mark(self, name):
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(self.dev)
+        now = self.time.perf_counter()
+        if name is not None:
+            self.out[name] = now - self.t
+        self.t = now
+
+
+def _hosted_flux(host, eng, image=None, prompt=None, prompt_2=None, negative_prompt=None, negative_prompt_2=None,
+                 true_cfg_scale: float = 1.0, height=None, width=None, num_inference_steps: int = 28, guidance_scale: float = 3.5,
+                 num_images_per_prompt: int = 1, generator=None, latents=None, prompt_embeds=None, pooled_prompt_embeds=None,
+                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type: str = "pil",
+                 return_dict: bool = True, max_sequence_length: int = 512, max_area: int = 1024 ** 2, _auto_resize: bool = True,
+                 preferred_resolutions=None, trace=None, **unused):
+    """FluxKontextPipeline.__call__ around the engine loop (RegionE/FluxKontext/inplace.py:112-240, :396-410)."""
+    dev = eng.transformer.device
+    clk = _Clock(dev)
+    multiple_of = host.vae_scale_factor * 2
+    preferred = PREFERRED_KONTEXT_RESOLUTIONS if preferred_resolutions is None else preferred_resolutions
+    # 1. image preprocessing (inplace.py:115-140)
+    if image is not None and not (isinstance(image, torch.Tensor) and image.size(1) == host.latent_channels):
+        img = image[0] if isinstance(image, list) else image
+        image_height, image_width = host.image_processor.get_default_height_width(img)
+        if _auto_resize and preferred:
+            ar = image_width / image_height
+            _, image_width, image_height = min((abs(ar - w / h), w, h) for w, h in preferred)
+        image_width, image_height = image_width // multiple_of * multiple_of, image_height // multiple_of * multiple_of
+        image = host.image_processor.resize(image, image_height, image_width)
+        image = host.image_processor.preprocess(image, image_height, image_width)
+        height, width = image.shape[-2], image.shape[-1]
+    else:
+        height = height or host.default_sample_size * host.vae_scale_factor
+        width = width or host.default_sample_size * host.vae_scale_factor
+        ar = width / height
+        width = round((max_area * ar) ** 0.5) // multiple_of * multiple_of
+        height = round((max_area / ar) ** 0.5) // multiple_of * multiple_of
+    # 2./3. prompts (inplace.py:142-208)
+    _one_image_only(prompt, num_images_per_prompt)
+    exec_dev = getattr(host, "_execution_device", dev)
+    has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None)
+    do_true_cfg = true_cfg_scale > 1 and has_neg
+    prompt_embeds, pooled_prompt_embeds, _ = host.encode_prompt(
+        prompt=prompt, prompt_2=prompt_2, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+        device=exec_dev, num_images_per_prompt=1, max_sequence_length=max_sequence_length, lora_scale=None)
+    if do_true_cfg:
+        negative_prompt_embeds, negative_pooled_prompt_embeds, _ = host.encode_prompt(
+            prompt=negative_prompt, prompt_2=negative_prompt_2, prompt_embeds=negative_prompt_embeds,
+            pooled_prompt_embeds=negative_pooled_prompt_embeds, device=exec_dev, num_images_per_prompt=1,
+            max_sequence_length=max_sequence_length, lora_scale=None)
+    # 4. latents: the host packs noise and the VAE-encoded condition image (inplace.py:210-226)
+    latents, image_latents, _, _ = host.prepare_latents(image, 1, eng.transformer.cfg_model.in_channels // 4, height, width,
+                                                        prompt_embeds.dtype, exec_dev, generator, latents)
+    if image_latents is None:
+        raise ValueError("FluxKontext editing needs a condition image")
+    clk.mark("encode_s")
+    # 5.-6. the denoise loop on the engine (inplace.py:228-394)
+    kw = dict(image=_bf(image_latents, dev), prompt_embeds=_bf(prompt_embeds, dev), pooled_prompt_embeds=_bf(pooled_prompt_embeds, dev),
+              height=height, width=width, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+              latents=_bf(latents, dev), return_dict=False, true_cfg_scale=true_cfg_scale,
+              negative_prompt_embeds=_bf(negative_prompt_embeds, dev) if do_true_cfg else None,
+              negative_pooled_prompt_embeds=_bf(negative_pooled_prompt_embeds, dev) if do_true_cfg else None)
+    if trace is not None:
+        kw["trace"] = trace
+    latents = eng(**kw)[0]
+    clk.mark("loop_s")
+    # 7. decode (inplace.py:396-410)
+    if output_type == "latent":
+        out = latents
+    else:
+        vae = host.vae
+        lat = host._unpack_latents(latents.to(vae.dtype if hasattr(vae, "dtype") else latents.dtype), height, width,
+                                   host.vae_scale_factor)
+        lat = lat / vae.config.scaling_factor + vae.config.shift_factor
+        out = host.image_processor.postprocess(vae.decode(lat, return_dict=False)[0], output_type=output_type)
+    if hasattr(host, "maybe_free_model_hooks"):
+        host.maybe_free_model_hooks()
+    clk.mark("decode_s")
+    return HostedOutput(out, clk.out) if return_dict else (out,)
+
+
+class _HostConnector:
+    """Step1X-Edit's text path in front of the trunk - the [EXT] Qwen2 `connector` (token refiner conditioned on the
+    TIMESTEP, so it runs once per computed step) and, in v1p2, `text_token_mapping` - stays on the host transformer
+    (Step1XEdit/inplace.py:514-516, Step1XEditV1P2/inplace.py:602-609); the engine's `connector` hook calls this object
+    and gets (context tokens, pooled vector rows) back.  Masks / text embeddings are bound per CFG branch."""
+
+    def __init__(self, host_tr, dev, masks, text=None):
+        self.tr, self.dev, self.masks, self.text = host_tr, dev, masks, text
+
+    def _one(self, enc, timestep, row):
+        mask = self.masks[row]
+        hdev = enc.device if mask is None else mask.device
+        e, y = self.tr.connector(enc.to(hdev), timestep.to(hdev), mask)
+        ttm = getattr(self.tr, "text_token_mapping", None)
+        if ttm is not None and self.text is not None and self.text[row] is not None:       # v1p2 :606-609
+            emb, tmask = self.text[row]
+            e = e + ttm(emb) * tmask[:, :, None]
+        return _bf(e, self.dev), _bf(y, self.dev)
+
+    def __call__(self, encoder_hidden_states, timestep, prompt_embeds_mask=None, tag=None):
+        if tag is not None:                                   # sequential CFG (v1p2): one branch per call
+            return self._one(encoder_hidden_states, timestep, 0 if tag == "cond" else 1)
+        outs = [self._one(encoder_hidden_states[b:b + 1], timestep[b:b + 1], b) for b in range(encoder_hidden_states.shape[0])]
+        return torch.cat([o[0] for o in outs], 0), [o[1] for o in outs]                    # batched CFG (v1p1)
+
+
+def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, true_cfg_scale: float = 6.0, height=None, width=None,
+                   num_inference_steps: int = 28, guidance_scale: float = 6.0, num_images_per_prompt: int = 1, generator=None,
+                   latents=None, prompt_embeds=None, prompt_embeds_mask=None, negative_prompt_embeds=None,
+                   negative_prompt_embeds_mask=None, output_type: str = "pil", return_dict: bool = True,
+                   timesteps_truncate: float = 0.93, process_norm_power: float = 0.4, size_level=None, trace=None, **unused):
+    """Step1XEditPipeline / Step1XEditPipelineV1P2 `__call__` around the engine loop (Step1XEdit/inplace.py:185-330,:437-455;
+    Step1XEditV1P2/inplace.py:214-300).  Not hosted: v1p2's thinking / reflection retry loop (VLM prompting, :192-212)."""
+    v1p2 = type(eng).__name__.endswith("V1P2")
+    dev = eng.transformer.device
+    clk = _Clock(dev)
+    exec_dev = getattr(host, "_execution_device", dev)
+    _one_image_only(prompt, num_images_per_prompt)
+    # 1. image (host.encode_image resizes, keeps the reference image for the VLM, remembers how to undo the resize)
+    args = (image, width, height, size_level, exec_dev, 1) if v1p2 else (image, width, height, exec_dev, 1)
+    image, ref_image, img_info, width, height = host.encode_image(*args)
+    # 2./3. prompts through the host's VLM encoder
+    has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_prompt_embeds_mask is not None)
+    if not has_neg:
+        negative_prompt = "" if image is not None else STEP1X_DEFAULT_NEGATIVE
+    if v1p2:          # encode_prompt returns a record: embedding / mask / txt_ids / text_embeds / text_masks (:241-254)
+        pos = host.encode_prompt(ref_image=ref_image, prompt=prompt, device=exec_dev, num_images_per_prompt=1)
+        neg = host.encode_prompt(ref_image=ref_image, prompt=negative_prompt, device=exec_dev, num_images_per_prompt=1)
+        prompt_embeds, prompt_embeds_mask = pos.embedding, pos.mask
+        negative_prompt_embeds, negative_prompt_embeds_mask = neg.embedding, neg.mask
+        text = [(pos.text_embeds, pos.text_masks), (neg.text_embeds, neg.text_masks)]
+        dtype = pos.embedding.dtype
+    else:
+        prompt_embeds, prompt_embeds_mask, _ = host.encode_prompt(
+            ref_image=ref_image, prompt=prompt, prompt_embeds=prompt_embeds, prompt_embeds_mask=prompt_embeds_mask,
+            device=exec_dev, num_images_per_prompt=1)
+        negative_prompt_embeds, negative_prompt_embeds_mask, _ = host.encode_prompt(
+            ref_image=ref_image, prompt=negative_prompt, prompt_embeds=negative_prompt_embeds,
+            prompt_embeds_mask=negative_prompt_embeds_mask, device=exec_dev, num_images_per_prompt=1)
+        text, dtype = None, prompt_embeds.dtype
+    # 4. latents
+    pl = (image, 1, eng.transformer.cfg_model.in_channels // 4, height, width, dtype, exec_dev, generator)
+    latents, image_latents, _, _ = host.prepare_latents(*pl) if v1p2 else host.prepare_latents(*pl, latents)
+    clk.mark("encode_s")
+    # 5.-6. loop on the engine; the host's connector feeds it per computed step
+    tr = eng.transformer
+    prev = tr.__dict__.get("connector")
+    tr.connector = _HostConnector(host.transformer, dev, [prompt_embeds_mask, negative_prompt_embeds_mask], text)
+    try:
+        kw = dict(image=_bf(image_latents, dev), prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
+                  pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None, height=height, width=width,
+                  num_inference_steps=num_inference_steps, true_cfg_scale=true_cfg_scale, guidance_scale=guidance_scale,
+                  latents=_bf(latents, dev), return_dict=False, timesteps_truncate=timesteps_truncate,
+                  process_norm_power=process_norm_power)
+        if trace is not None:
+            kw["trace"] = trace
+        latents = eng(**kw)[0]
+    finally:
+        if prev is None:
+            tr.__dict__.pop("connector", None)
+        else:
+            tr.connector = prev
+    clk.mark("loop_s")
+    # 7. decode (:437-446)
+    if output_type == "latent":
+        out = latents
+    else:
+        vae = host.vae
+        lat = host._unpack_latents(latents.to(getattr(vae, "dtype", latents.dtype)), height, width, host.vae_scale_factor)
+        lat = lat / vae.config.scaling_factor + vae.config.shift_factor
+        out = host.image_processor.postprocess(vae.decode(lat, return_dict=False)[0], output_type=output_type)
+        out = host._output_process_image(out, img_info)
+    if hasattr(host, "maybe_free_model_hooks"):
+        host.maybe_free_model_hooks()
+    clk.mark("decode_s")
+    return HostedOutput(out, clk.out) if return_dict else (out,)
+
+
+def _qwen_dims(target_area, ratio):
+    """calculate_dimensions (QwenImageEdit/utils.py:96-103)."""
+    import math
+    width = math.sqrt(target_area * ratio)
+    height = width / ratio
+    return round(width / 32) * 32, round(height / 32) * 32
+
+
+def _hosted_qwen(host, eng, image=None, prompt=None, negative_prompt=None, true_cfg_scale: float = 4.0, height=None, width=None,
+                 num_inference_steps: int = 28, guidance_scale=None, num_images_per_prompt: int = 1, generator=None, latents=None,
+                 prompt_embeds=None, prompt_embeds_mask=None, negative_prompt_embeds=None, negative_prompt_embeds_mask=None,
+                 output_type: str = "pil", return_dict: bool = True, max_sequence_length: int = 512, trace=None, **unused):
+    """QwenImageEditPipeline / QwenImageEditPlusPipeline `__call__` around the engine loop (QwenImageEdit/inplace.py:180-330,
+    :434-455; QwenImageEditPlus/inplace.py:189-300: a LIST of condition images, each resized twice - 384^2 area for the VLM,
+    1024^2 area for the VAE - the last one fixing the output size)."""
+    plus = "Plus" in type(eng).__name__
+    dev = eng.transformer.device
+    clk = _Clock(dev)
+    exec_dev = getattr(host, "_execution_device", dev)
+    _one_image_only(prompt, num_images_per_prompt)
+    imgs = image if isinstance(image, list) else [image]
+    ref = imgs[-1] if plus else imgs[0]
+    ref_w, ref_h = ref.size if hasattr(ref, "size") and not isinstance(ref, torch.Tensor) else (ref.shape[-1], ref.shape[-2])
+    calc_w, calc_h = _qwen_dims(1024 * 1024, ref_w / ref_h)
+    height, width = height or calc_h, width or calc_w
+    multiple_of = host.vae_scale_factor * 2
+    width, height = width // multiple_of * multiple_of, height // multiple_of * multiple_of
+    tok = lambda px: px // host.vae_scale_factor // 2
+    is_latent = isinstance(image, torch.Tensor) and image.size(1) == getattr(host, "latent_channels", -1)
+    if plus and not is_latent:
+        prompt_image, vae_images, cond_shapes = [], [], []
+        for img in imgs:
+            iw, ih = img.size if hasattr(img, "size") and not isinstance(img, torch.Tensor) else (img.shape[-1], img.shape[-2])
+            cw, ch = _qwen_dims(QWEN_CONDITION_IMAGE_SIZE, iw / ih)
+            vw, vh = _qwen_dims(QWEN_VAE_IMAGE_SIZE, iw / ih)
+            prompt_image.append(host.image_processor.resize(img, ch, cw))
+            vae_images.append(host.image_processor.preprocess(img, vh, vw).unsqueeze(2))
+            cond_shapes.append((tok(vh), tok(vw)))
+        image = vae_images
+    elif not is_latent:
+        image = host.image_processor.resize(image, calc_h, calc_w)
+        prompt_image = image
+        image = host.image_processor.preprocess(image, calc_h, calc_w).unsqueeze(2)
+        cond_shapes = [(tok(calc_h), tok(calc_w))]
+    else:
+        prompt_image, cond_shapes = None, None
+    has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_prompt_embeds_mask is not None)
+    do_true_cfg = true_cfg_scale > 1 and has_neg
+    enc = lambda p, e, m: host.encode_prompt(image=prompt_image, prompt=p, prompt_embeds=e, prompt_embeds_mask=m, device=exec_dev,
+                                             num_images_per_prompt=1, max_sequence_length=max_sequence_length)
+    prompt_embeds, prompt_embeds_mask = enc(prompt, prompt_embeds, prompt_embeds_mask)
+    if do_true_cfg:
+        negative_prompt_embeds, negative_prompt_embeds_mask = enc(negative_prompt, negative_prompt_embeds, negative_prompt_embeds_mask)
+    latents, image_latents = host.prepare_latents(image, 1, eng.transformer.cfg_model.in_channels // 4, height, width,
+                                                  prompt_embeds.dtype, exec_dev, generator, latents)
+    clk.mark("encode_s")
+    kw = dict(image=_bf(image_latents, dev), prompt_embeds=_bf(prompt_embeds, dev),
+              negative_prompt_embeds=_bf(negative_prompt_embeds, dev) if do_true_cfg else None, height=height, width=width,
+              num_inference_steps=num_inference_steps, true_cfg_scale=true_cfg_scale, latents=_bf(latents, dev),
+              return_dict=False, cond_shapes=cond_shapes)
+    if trace is not None:
+        kw["trace"] = trace
+    latents = eng(**kw)[0]
+    clk.mark("loop_s")
+    if output_type == "latent":
+        out = latents
+    else:                                                                                  # QwenImageEdit/inplace.py:437-451
+        vae = host.vae
+        lat = host._unpack_latents(latents, height, width, host.vae_scale_factor).to(vae.dtype)
+        mean = torch.tensor(vae.config.latents_mean).view(1, vae.config.z_dim, 1, 1, 1).to(lat.device, lat.dtype)
+        inv_std = 1.0 / torch.tensor(vae.config.latents_std).view(1, vae.config.z_dim, 1, 1, 1).to(lat.device, lat.dtype)
+        out = host.image_processor.postprocess(vae.decode(lat / inv_std + mean, return_dict=False)[0][:, :, 0], output_type=output_type)
+    if hasattr(host, "maybe_free_model_hooks"):
+        host.maybe_free_model_hooks()
+    clk.mark("decode_s")
+    return HostedOutput(out, clk.out) if return_dict else (out,)
+
+
+_HOSTED = {"FluxKontextPipeline": _hosted_flux, "Step1XEditPipeline": _hosted_step1x, "Step1XEditPipelineV1P2": _hosted_step1x,
+           "QwenImageEditPipeline": _hosted_qwen, "QwenImageEditPlusPipeline": _hosted_qwen}
+
+
+def is_engine_pipeline(pipe) -> bool:
+    """True for a regione_amd.harness pipeline (latent-level, HIP transformer); False for a stock host pipeline."""
+    from .harness import flux as HF
+    return isinstance(getattr(pipe, "transformer", None), HF.FluxTransformer2DModel)
+
+
+class HostedPipeline:
+    """Wrapper object: `hosted(image=..., prompt=...)` = host pre / post-processing + engine loop.  `RegionEHelper(hosted)`
+    patches the engine.  (RegionEHelper(pipe) on the stock pipeline itself is the reference's call shape - see attach.)"""
 
     def __init__(self, host, engine):
         self.host, self._regione_engine = host, engine
+        self._call = _HOSTED[_host_name(host)]
 
     @property
     def engine(self):
         return self._regione_engine
 
     @torch.no_grad()
-    def __call__(self, image=None, prompt=None, prompt_2=None, negative_prompt=None, negative_prompt_2=None,
-                 true_cfg_scale: float = 1.0, height=None, width=None, num_inference_steps: int = 28, guidance_scale: float = 3.5,
-                 num_images_per_prompt: int = 1, generator=None, latents=None, prompt_embeds=None, pooled_prompt_embeds=None,
-                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type: str = "pil",
-                 return_dict: bool = True, max_sequence_length: int = 512, max_area: int = 1024 ** 2, _auto_resize: bool = True,
-                 preferred_resolutions=None, trace=None):
-        host, eng = self.host, self._regione_engine
-        dev = eng.transformer.device
-        multiple_of = host.vae_scale_factor * 2
-        # 1. image preprocessing (inplace.py:115-140)
-        if image is not None and not (isinstance(image, torch.Tensor) and image.size(1) == host.latent_channels):
-            img = image[0] if isinstance(image, list) else image
-            image_height, image_width = host.image_processor.get_default_height_width(img)
-            if _auto_resize and preferred_resolutions:
-                ar = image_width / image_height
-                _, image_width, image_height = min((abs(ar - w / h), w, h) for w, h in preferred_resolutions)
-            image_width, image_height = image_width // multiple_of * multiple_of, image_height // multiple_of * multiple_of
-            image = host.image_processor.resize(image, image_height, image_width)
-            image = host.image_processor.preprocess(image, image_height, image_width)
-            height, width = image.shape[-2], image.shape[-1]
-        else:
-            height = height or host.default_sample_size * host.vae_scale_factor
-            width = width or host.default_sample_size * host.vae_scale_factor
-            ar = width / height
-            width = round((max_area * ar) ** 0.5) // multiple_of * multiple_of
-            height = round((max_area / ar) ** 0.5) // multiple_of * multiple_of
-        # 2./3. prompts (inplace.py:142-208)
-        if num_images_per_prompt != 1 or (isinstance(prompt, list) and len(prompt) != 1):
-            raise ValueError("the region-aware loop is batch-1 (token_selector squeezes the batch, utils.py:337-343): "
-                             "one image per call, shard images across GPUs")
-        exec_dev = getattr(host, "_execution_device", dev)
-        has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None)
-        do_true_cfg = true_cfg_scale > 1 and has_neg
-        prompt_embeds, pooled_prompt_embeds, _ = host.encode_prompt(
-            prompt=prompt, prompt_2=prompt_2, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
-            device=exec_dev, num_images_per_prompt=1, max_sequence_length=max_sequence_length, lora_scale=None)
-        if do_true_cfg:
-            negative_prompt_embeds, negative_pooled_prompt_embeds, _ = host.encode_prompt(
-                prompt=negative_prompt, prompt_2=negative_prompt_2, prompt_embeds=negative_prompt_embeds,
-                pooled_prompt_embeds=negative_pooled_prompt_embeds, device=exec_dev, num_images_per_prompt=1,
-                max_sequence_length=max_sequence_length, lora_scale=None)
-        # 4. latents: the host packs noise and the VAE-encoded condition image (inplace.py:210-226)
-        latents, image_latents, _, _ = host.prepare_latents(image, 1, eng.transformer.cfg_model.in_channels // 4, height, width,
-                                                            prompt_embeds.dtype, exec_dev, generator, latents)
-        if image_latents is None:
-            raise ValueError("FluxKontext editing needs a condition image")
-        bf = lambda t: t.to(device=dev, dtype=torch.bfloat16) if t is not None else None
-        # 5.-6. the denoise loop on the engine (inplace.py:228-394)
-        kw = dict(image=bf(image_latents), prompt_embeds=bf(prompt_embeds), pooled_prompt_embeds=bf(pooled_prompt_embeds),
-                  height=height, width=width, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                  latents=bf(latents), return_dict=False, true_cfg_scale=true_cfg_scale,
-                  negative_prompt_embeds=bf(negative_prompt_embeds) if do_true_cfg else None,
-                  negative_pooled_prompt_embeds=bf(negative_pooled_prompt_embeds) if do_true_cfg else None)
-        if trace is not None:
-            kw["trace"] = trace
-        latents = eng(**kw)[0]
-        # 7. decode (inplace.py:396-410)
-        if output_type == "latent":
-            out = latents
-        else:
-            vae = host.vae
-            lat = host._unpack_latents(latents.to(vae.dtype if hasattr(vae, "dtype") else latents.dtype), height, width,
-                                       host.vae_scale_factor)
-            lat = lat / vae.config.scaling_factor + vae.config.shift_factor
-            out = host.image_processor.postprocess(vae.decode(lat, return_dict=False)[0], output_type=output_type)
-        if hasattr(host, "maybe_free_model_hooks"):
-            host.maybe_free_model_hooks()
-        return HostedOutput(out) if return_dict else (out,)
+    def __call__(self, *a, **kw):
+        if a:
+            raise TypeError("pass the pipeline arguments by keyword (image=..., prompt=...)")
+        return self._call(self.host, self._regione_engine, **kw)
+
+
+HostedFluxKontextPipeline = HostedPipeline          # round-1 name
+
+
+def _host_name(pipe) -> str:
+    cls = getattr(pipe, "_regione_host_class", None) or pipe.__class__
+    return cls.__name__
 
 
 def adopt(pipe, device="cuda"):
-    """Hosted pipeline (image + prompt in, image out) - FLUX.1 Kontext this round; the CFG families' prompt paths go through
-    their VLM encoders and are adopted at the latent level (`adopt_engine`)."""
-    if pipe.__class__.__name__ != "FluxKontextPipeline":
-        raise NotImplementedError(f"hosted call for {pipe.__class__.__name__} is not built yet: use adopt_engine(pipe) and feed "
-                                  "prompt embeddings / packed latents")
-    return HostedFluxKontextPipeline(pipe, adopt_engine(pipe, device))
+    """Hosted wrapper (image + prompt in, image out) for any of the five pipeline classes."""
+    if _host_name(pipe) not in _HOSTED:
+        raise NotImplementedError(f"no hosted call for {pipe.__class__.__name__}")
+    return HostedPipeline(pipe, attach(pipe, device))
+
+
+def attach(pipe, device="cuda"):
+    """Adopt the host pipeline's transformer once and keep the engine ON the host object (`pipe._regione_engine`)."""
+    eng = pipe.__dict__.get("_regione_engine") if hasattr(pipe, "__dict__") else None
+    if eng is None:
+        eng = adopt_engine(pipe, device)
+        pipe._regione_engine = eng
+    return eng
+
+
+def swap_host_class(pipe):
+    """Hook (1) of the reference (`pipeline.__class__ = RegionE<...>Pipeline`, inplace.py:53-62) on the HOST object: a
+    subclass of the host's own class whose `__call__` is the hosted call.  The user keeps calling `pipe(...)`."""
+    if getattr(pipe, "_regione_host_class", None) is not None:
+        return pipe
+    base = pipe.__class__
+    call = _HOSTED[base.__name__]
+
+    @torch.no_grad()
+    def __call__(self, *a, **kw):
+        if a:
+            raise TypeError("pass the pipeline arguments by keyword (image=..., prompt=...)")
+        return call(self, self._regione_engine, **kw)
+    pipe._regione_host_class = base
+    pipe.__class__ = type("RegionE" + base.__name__, (base,), {"__call__": __call__})
+    return pipe
+
+
+def restore_host_class(pipe):
+    base = getattr(pipe, "_regione_host_class", None)
+    if base is not None:
+        pipe.__class__ = base
+        pipe._regione_host_class = None
+    return pipe

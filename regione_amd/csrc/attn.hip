@@ -340,10 +340,12 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g
 template <int NW, int NSTAGE, bool SPLIT>
 static int launch_attention(const AttnArgs& g, hipStream_t st) {
     constexpr int LDS = NSTAGE * ATT_STAGE;
-    static bool attr = false;
-    if (!attr) {
+    static bool attr[64] = {};          // per device (one process may drive several GPUs)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr[dev]) {
         (void)hipFuncSetAttribute((const void*)attention_kernel<NW, NSTAGE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
+        if (dev >= 0 && dev < 64) attr[dev] = true;
     }
     const int nblocks = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
     if (nblocks == 0) return 0;

@@ -144,6 +144,7 @@ struct GemmGroup {
     // MODE 2 sums the partials of each tile and runs the normal epilogue.
     int tile_offset, nt_launch, nsplit;
     float* ws;
+    int dbg;            // timing experiments only (RGN_GEMM_DBG): bit 0 = skip the epilogue (results are garbage)
 };
 
 constexpr int MODE_FULL = 0, MODE_PARTIAL = 1, MODE_REDUCE = 2;
@@ -188,14 +189,16 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16x16 MFMA tiles per wave
     constexpr bool ASM4W = (BM == 256 && BN == 256 && WM == 2 && WN == 2);
-    static_assert(!ASM4W || MODE == MODE_FULL, "the hand-scheduled variant only runs whole-K tiles");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB DMA pieces per wave per stage
     constexpr int CT_LD = BN + 8;                              // padded bf16 row of the C staging tile
     // C rows staged per epilogue chunk: one wave row at a time (the staging tile then fits inside the K-loop
     // stages), except for the fused Q/K/V epilogue, which stages the whole tile at once so that no wave keeps its
     // 128 accumulator registers alive while the others run the (register-hungry) norm / RoPE passes
-    constexpr int NCH = (EPI == RGN_EPI_QKV) ? 1 : WM;
+    // ... and for the 4-wave asm variant (each wave holds 64 fragments: with per-wave-row chunks only half the waves
+    // stage at a time and the epilogue costs ~9 us per tile instead of ~4; measured with RGN_GEMM_DBG=1 K sweeps)
+    // (the gated-residual epilogue keeps per-wave-row chunks: its residual prefetch would need 128 registers for a whole tile)
+    constexpr int NCH = (EPI == RGN_EPI_QKV || (BM == 256 && WM * WN == 4 && EPI != RGN_EPI_GATE_RESID)) ? 1 : WM;
     constexpr int CROWS = BM / NCH;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -278,6 +281,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
         k_begin = split * per;
         nk = max(0, min(per, nk_all - k_begin));
     }
+    // 4-wave variant: the bias of this lane's 8 x 4 columns is requested BEFORE the K loop (one L2 round trip hidden under
+    // the loop); fetched inside the staging loop, hipcc waits vmcnt(0) behind each of the 8 loads - 8 serialised round
+    // trips, ~5 of the ~9 us this variant's epilogue used to cost
+    uint2 bias_pre[ASM4W ? TN : 1];
+    if constexpr (ASM4W) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 16 + (lane >> 4) * 4;
+            bias_pre[j] = (g.bias != nullptr && col + 4 <= g.N) ? *(const uint2*)(g.bias + col) : make_uint2(0u, 0u);
+        }
+    }
     if constexpr (ASM4W) {
         // ---- hand-scheduled K loop (tools/gen_gemm_loop.py): per-lane SOURCE byte offsets of this wave's 8 + 8 DMA pieces
         // (same swizzled image as stage()), LDS fragment addresses of stage 0, buffer resources, loop count ----
@@ -306,8 +320,10 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
         };
         const u32x4_s pa = rsrc(g.A), pw = rsrc(g.W);
         uint32_t stg = __builtin_amdgcn_readfirstlane(lds0 + wave * (PA * 1024));
-        uint32_t koff = 0;
-        if constexpr (AV == 0) {
+        uint32_t koff = __builtin_amdgcn_readfirstlane(k_begin * (BK * 2));       // byte offset of the first K tile (split-K piece)
+        if constexpr (MODE == MODE_REDUCE) {
+            // no K loop: the accumulators are the sums of the partial fragments, read by the epilogue below
+        } else if constexpr (AV == 0) {
             uint32_t cnt = __builtin_amdgcn_readfirstlane(nk - 2);
             asm volatile(RGN_GEMM_LOOP4W_ASM
                          : [la0] "+&v"(la0), [la1] "+&v"(la1), [lb0] "+&v"(lb0), [lb1] "+&v"(lb1), [cnt] "+&s"(cnt), [stg] "+&s"(stg),
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
             uint32_t cnt = __builtin_amdgcn_readfirstlane(nk - 3);
             const uint32_t lbo0 = lb0 - lds0, lbo1 = lb1 - lds0;
             const uint32_t wwrap = __builtin_amdgcn_readfirstlane(lds0 + 65536 + wave * (PB * 1024));
-            uint32_t was = wwrap, wrd = __builtin_amdgcn_readfirstlane(lds0 + 65536), kofw = 0;
+            uint32_t was = wwrap, wrd = __builtin_amdgcn_readfirstlane(lds0 + 65536), kofw = koff;
             asm volatile(RGN_GEMM_LOOP4W_RING_ASM
                          : [la0] "+&v"(la0), [la1] "+&v"(la1), [lb0] "=&v"(lb0), [lb1] "=&v"(lb1), [cnt] "+&s"(cnt), [stg] "+&s"(stg),
                            [koff] "+&s"(koff), [was] "+&s"(was), [wrd] "+&s"(wrd), [kofw] "+&s"(kofw)
@@ -359,6 +375,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
         }
     }
     }
+    if (gg.dbg & 1) return;
+    if constexpr (MODE == MODE_PARTIAL && ASM4W) {
+        float4* w = (float4*)gg.ws + ((size_t)unit * gg.nsplit + split) * (size_t)(TM * TN * NT) + tid;
+        static_for<TM * TN>([&](auto Fc) {
+            constexpr int F = decltype(Fc)::value;
+            float c[4];
+            agpr_read4<F * 4>(c);
+            w[(size_t)F * NT] = make_float4(c[0], c[1], c[2], c[3]);
+        });
+        return;
+    }
     if (MODE == MODE_PARTIAL) {
         // lane-linear fp32 fragment dump: [unit][split][fragment (i,j)][thread] float4 - fully coalesced
         float4* w = (float4*)gg.ws + ((size_t)unit * gg.nsplit + split) * (size_t)(TM * TN * NT) + tid;
@@ -369,7 +396,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                 w[(size_t)(i * TN + j) * NT] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         return;
     }
-    if (MODE == MODE_REDUCE) {
+    if (MODE == MODE_REDUCE && !ASM4W) {
         const float4* w = (const float4*)gg.ws + (size_t)unit * gg.nsplit * (size_t)(TM * TN * NT) + tid;
         for (int sp = 0; sp < gg.nsplit; ++sp) {
 #pragma unroll
@@ -420,7 +447,9 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                 float bv[4] = {0.f, 0.f, 0.f, 0.f};
                 if (g.bias != nullptr) {
                     if (n0 + nl + 4 <= g.N) {
-                        const uint2 b2 = *(const uint2*)(g.bias + n0 + nl);
+                        uint2 b2;
+                        if constexpr (ASM4W) b2 = bias_pre[j];
+                        else b2 = *(const uint2*)(g.bias + n0 + nl);
                         bv[0] = bf2f(b2.x & 0xffff); bv[1] = bf2f(b2.x >> 16); bv[2] = bf2f(b2.y & 0xffff); bv[3] = bf2f(b2.y >> 16);
                     } else {
                         for (int r = 0; r < 4; ++r) if (n0 + nl + r < g.N) bv[r] = bf2f(g.bias[n0 + nl + r]);
@@ -448,7 +477,17 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                             static_for<TM>([&](auto Ic) {
                                 constexpr int I = decltype(Ic)::value;
                                 float c[4];
-                                agpr_read4<(I * TN + J) * 4>(c);
+                                if constexpr (MODE == MODE_REDUCE) {
+                                    // sum of this fragment's split-K partials (same lane-linear layout as the dump)
+                                    const float4* w = (const float4*)gg.ws + (size_t)unit * gg.nsplit * (size_t)(TM * TN * NT) + tid;
+                                    c[0] = c[1] = c[2] = c[3] = 0.f;
+                                    for (int sp = 0; sp < gg.nsplit; ++sp) {
+                                        const float4 v = w[(size_t)(sp * TM * TN + I * TN + J) * NT];
+                                        c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
+                                    }
+                                } else {
+                                    agpr_read4<(I * TN + J) * 4>(c);
+                                }
                                 put(I, c);
                             });
                         }
@@ -646,8 +685,10 @@ using namespace rgn;
 
 template <int BM, int BN, int WM, int WN, int MODE, int AV = 0>
 static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
-    constexpr int LDS = (AV == 1) ? 160 * 1024 : 2 * (BM + BN) * BK * 2;
     constexpr int QKV_TILE = BM * (BN + 8) * 2 + BM * 4;            // whole staged C tile + cache-row table
+    constexpr bool ASM4W = (BM == 256 && WM * WN == 4);
+    constexpr int LDS_LOOP = (AV == 1) ? 160 * 1024 : 2 * (BM + BN) * BK * 2;
+    constexpr int LDS = (ASM4W && QKV_TILE > LDS_LOOP) ? QKV_TILE : LDS_LOOP;     // the asm variant stages the whole C tile
     constexpr int LDS_QKV = QKV_TILE > LDS ? QKV_TILE : LDS;
     constexpr int NT = 64 * WM * WN;
     // the opt-in is per device (one process may drive several GPUs): remember which devices have it
@@ -757,16 +798,24 @@ static float estimate128(int nt, int K, double flops) {
     return fmaxf(t, (float)(flops / 1.05e15 * 1e6));
 }
 
-// whole-K launches of the 256x256 configuration: the hand-scheduled 4-wave kernel where it applies
-template <int BM, int BN, int WM, int WN>
-static int launch_full(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_t st) {
+// launches of the 256x256 configuration: the hand-scheduled 4-wave geometry where it applies (a split-K remainder's
+// PARTIAL and REDUCE launches must use the SAME geometry: the partial fragments are stored lane-linear)
+template <int BM, int BN, int WM, int WN, int MODE>
+static int launch_mode(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_t st) {
     if constexpr (BM == 256 && BN == 256) {
         // RGN_GEMM_ASMV: 0 = two 64 KiB stages, 1 = A ring of two + W ring of three 32 KiB slots (needs >= 4 K tiles)
         static const int asmv = [] { const char* e = getenv("RGN_GEMM_ASMV"); return e ? atoi(e) : 1; }();
-        if (asm4w && asmv == 1 && gg.p[0].K >= 4 * BK) return launch_gemm<256, 256, 2, 2, MODE_FULL, 1>(gg, epilogue, st);
-        if (asm4w) return launch_gemm<256, 256, 2, 2, MODE_FULL, 0>(gg, epilogue, st);
+        int nk = gg.p[0].K / BK;
+        if (MODE == MODE_PARTIAL) {                       // shortest split piece
+            const int per = (nk + gg.nsplit - 1) / gg.nsplit;
+            nk = nk - (gg.nsplit - 1) * per;
+        }
+        if constexpr (MODE == MODE_FULL) {
+            if (asm4w && asmv == 1 && nk >= 4) return launch_gemm<256, 256, 2, 2, MODE, 1>(gg, epilogue, st);
+            if (asm4w) return launch_gemm<256, 256, 2, 2, MODE, 0>(gg, epilogue, st);
+        }
     }
-    return launch_gemm<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, st);
+    return launch_gemm<BM, BN, WM, WN, MODE>(gg, epilogue, st);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -777,18 +826,26 @@ static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, voi
     if ((v && v[0] == '0') || left == 0) nsplit = 1;
     gg.ws = (float*)ws;
     gg.nsplit = 1;
+    static const int dbg = [] { const char* e = getenv("RGN_GEMM_DBG"); return e ? atoi(e) : 0; }();
+    gg.dbg = dbg;
     int rc;
     if (nsplit == 1) {
         gg.tile_offset = 0; gg.nt_launch = nt;
-        return launch_full<BM, BN, WM, WN>(gg, epilogue, asm4w, st);
+        return launch_mode<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, asm4w, st);
     }
     if (full > 0) {
         gg.tile_offset = 0; gg.nt_launch = full;
-        if ((rc = launch_full<BM, BN, WM, WN>(gg, epilogue, asm4w, st))) return rc;
+        if ((rc = launch_mode<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, asm4w, st))) return rc;
     }
     gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = nsplit;
-    if ((rc = launch_gemm<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, st))) return rc;
-    return launch_gemm<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, st);
+    // the split pieces of the asm geometry need >= 2 K tiles each (>= 4 for the ring variant, checked in launch_mode)
+    const int nk_all = gg.p[0].K / BK, per = (nk_all + nsplit - 1) / nsplit;
+    // the split remainder stays on the 8-wave geometry: a 4-wave reduce pass (64 fragments per thread, each the sum of
+    // nsplit dependent-latency loads) measured 1.5 - 3x slower than the 8-wave one (txt ff2 473 -> 155 TFLOP/s)
+    const bool asm_split = false;
+    (void)nk_all; (void)per;
+    if ((rc = launch_mode<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, asm_split, st))) return rc;
+    return launch_mode<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, asm_split, st);
 }
 
 static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_t ws_bytes, hipStream_t st) {

@@ -293,12 +293,8 @@ static int launch_morph(const uint8_t* raw, int H, int W, int ed, int64_t* e, in
     const int L = H * W;
     const size_t lds = 2 * (size_t)((L + 15) & ~15);
     if (lds > 150 * 1024) return fail(RGN_E_UNSUPPORTED, "arp: token grid larger than 76800 tokens");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)arp_morph_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            150 * 1024);
-        attr_set = true;
-    }
+    if (lds > 64 * 1024)          // the opt-in is per device and costs nothing next to the launch: no process-wide flag
+        (void)hipFuncSetAttribute((const void*)arp_morph_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipLaunchKernelGGL(arp_morph_compact_kernel, dim3(1), dim3(1024), lds, st, raw, H, W, ed, e, u, mask, count);
     return check_launch("arp_morph_compact_kernel");
 }

@@ -41,9 +41,12 @@ def init(backend: str, device: Optional[torch.device] = None):
     return dist
 
 
-def gather_latents(local: Sequence[torch.Tensor], image_ids: Sequence[int], n_images: int, dist=None) -> List[Optional[torch.Tensor]]:
+def gather_latents(local: Sequence[torch.Tensor], image_ids: Sequence[int], n_images: int, dist=None,
+                   like: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """Every rank ends up with the latents of all images, in image order.  Ranks may hold different
-    numbers of images (ragged batch): shorter ranks pad with a dummy that is dropped again."""
+    numbers of images (ragged batch, down to NONE when n_images < world size): shorter ranks pad with a dummy that is
+    dropped again.  All images must share one latent shape; a rank without images learns it from `like` (a template
+    tensor) or, failing that, from rank 0 (one small broadcast) - it must never enter the collective empty-handed."""
     if dist is None or dist.get_world_size() == 1:
         out: List[Optional[torch.Tensor]] = [None] * n_images
         for j, t in zip(image_ids, local):
@@ -52,9 +55,20 @@ def gather_latents(local: Sequence[torch.Tensor], image_ids: Sequence[int], n_im
     world = dist.get_world_size()
     per = (n_images + world - 1) // world
     out = [None] * n_images
+    template = local[0] if len(local) else like
+    if n_images < world:
+        # some ranks own no image (image j lives on rank j % world): every rank learns the latent shape from rank 0, which
+        # always owns image 0 - the same collective sequence on every rank, nobody enters all_gather empty-handed
+        meta = [(tuple(local[0].shape), str(local[0].dtype).replace("torch.", ""))] if dist.get_rank() == 0 else [None]
+        dist.broadcast_object_list(meta, src=0)
+        if template is None:
+            shape, dt = meta[0]
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+            template = torch.zeros(shape, dtype=getattr(torch, dt), device=dev)
+    assert template is not None, "a rank without images needs n_images < world size (round-robin placement) or `like`"
     for slot in range(per):
         have = slot < len(local)
-        mine = local[slot] if have else torch.zeros_like(local[0])
+        mine = local[slot] if have else torch.zeros_like(template)
         dev = mine.device
         if dist.get_backend() == "gloo" and mine.is_cuda:      # debugging path: gloo collectives run on host tensors
             mine = mine.cpu()

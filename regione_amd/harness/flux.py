@@ -58,10 +58,27 @@ class FlowMatchEulerDiscreteScheduler:
 
     order = 1
 
+    # config keys this restatement implements (diffusers FlowMatchEulerDiscreteScheduler [EXT]); a host scheduler whose
+    # config sets any OTHER key to a non-default value would run a different sigma schedule than the reference's
+    # `from_config` copy (inplace.py:56) - refused instead of silently ignored (advisor finding, round 1)
+    DEFAULTS = dict(num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
+                    base_image_seq_len=256, max_image_seq_len=4096, invert_sigmas=False, shift_terminal=None,
+                    use_karras_sigmas=False, use_exponential_sigmas=False, use_beta_sigmas=False,
+                    time_shift_type="exponential", stochastic_sampling=False)
+    UNIMPLEMENTED = ("use_karras_sigmas", "use_exponential_sigmas", "use_beta_sigmas", "stochastic_sampling")
+
     def __init__(self, **config):
-        cfg = dict(num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=1.15,
-                   base_image_seq_len=256, max_image_seq_len=4096, stochastic_sampling=False)
-        cfg.update(config)
+        cfg = dict(self.DEFAULTS)
+        for k, v in config.items():
+            if k.startswith("_"):                 # diffusers bookkeeping (_class_name, _diffusers_version, ...)
+                continue
+            if k not in cfg:
+                raise ValueError(f"scheduler config key {k!r} is not implemented by the HIP engine's scheduler")
+            if k in self.UNIMPLEMENTED and v:
+                raise ValueError(f"scheduler config {k}={v!r} is not implemented by the HIP engine's scheduler")
+            cfg[k] = v
+        if cfg["time_shift_type"] not in ("exponential", "linear"):
+            raise ValueError(f"time_shift_type {cfg['time_shift_type']!r}")
         self.config = _Cfg(cfg)
         self.sigmas = None
         self.timesteps = None
@@ -79,18 +96,40 @@ class FlowMatchEulerDiscreteScheduler:
     def set_begin_index(self, begin_index: int = 0):
         self._begin_index = begin_index
 
+    def time_shift(self, mu, sigma, t):
+        if self.config.time_shift_type == "linear":
+            return mu / (mu + (1 / t - 1) ** sigma)
+        return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+    def stretch_shift_to_terminal(self, t):
+        """[EXT] stretch the shifted schedule so that it ends at `shift_terminal` (Qwen-Image-Edit's published scheduler
+        config sets 0.02): 1 - (1 - t) / ((1 - t[-1]) / (1 - shift_terminal)), float32 like the array it is applied to."""
+        one_minus_z = 1 - t
+        scale_factor = one_minus_z[-1] / np.float32(1 - self.config.shift_terminal)
+        return (1 - (one_minus_z / scale_factor)).astype(np.float32)
+
     def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
         if sigmas is None:
             sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
         sigmas = np.array(sigmas).astype(np.float32)
         if self.config.use_dynamic_shifting:
-            sigmas = math.exp(mu) / (math.exp(mu) + (1 / sigmas - 1) ** 1.0)
+            if mu is None:
+                raise ValueError("`mu` must be passed when `use_dynamic_shifting` is set")
+            sigmas = self.time_shift(mu, 1.0, sigmas)
         else:
             s = self.config.shift
             sigmas = s * sigmas / (1 + (s - 1) * sigmas)
-        sigmas = torch.from_numpy(np.asarray(sigmas, dtype=np.float32))
-        self.timesteps = sigmas * self.config.num_train_timesteps
-        self.sigmas = torch.cat([sigmas, torch.zeros(1)])
+        sigmas = np.asarray(sigmas, dtype=np.float32)
+        if self.config.shift_terminal:
+            sigmas = self.stretch_shift_to_terminal(sigmas)
+        sigmas = torch.from_numpy(sigmas)
+        if self.config.invert_sigmas:
+            sigmas = 1.0 - sigmas
+            self.timesteps = sigmas * self.config.num_train_timesteps
+            self.sigmas = torch.cat([sigmas, torch.ones(1)])
+        else:
+            self.timesteps = sigmas * self.config.num_train_timesteps
+            self.sigmas = torch.cat([sigmas, torch.zeros(1)])
         self.num_inference_steps = len(self.timesteps)
         self._step_index = None
 
@@ -534,8 +573,10 @@ class FluxTransformer2DModel:
         ops.gemm(ops.silu(temb), self.mod_w, self.mod_b, table)
         if not hasattr(self, "_mod_tables") or len(self._mod_tables) > 4:
             self._mod_tables = {}
+        # the entry HOLDS the pooled tensor: its address cannot be recycled for another prompt while the table lives, and a
+        # lookup checks identity, not just the address
         self._mod_tables[0 if pooled is None else pooled.data_ptr()] = dict(keys={k: i for i, k in enumerate(keys)}, table=table,
-                                                   guidance=None if gd is None else float(gd[0]))
+                                                   guidance=None if gd is None else float(gd[0]), pooled=pooled)
 
     def clear_modulations(self):
         self._mod_tables = {}
@@ -552,7 +593,7 @@ class FluxTransformer2DModel:
 
     def _lookup_modulation(self, ts, gd, pooled) -> Optional[Modulation]:
         mt = getattr(self, "_mod_tables", {}).get(0 if pooled is None else pooled.data_ptr())
-        if mt is None or mt["guidance"] != (None if gd is None else float(gd[0])):
+        if mt is None or mt["pooled"] is not pooled or mt["guidance"] != (None if gd is None else float(gd[0])):
             return None
         i = mt["keys"].get(float(ts[0]))
         return None if i is None else Modulation(mt["table"][i:i + 1], self.cfg_model.d)

@@ -103,11 +103,22 @@ class QwenImagePipelineOutput(H._Cfg):
 class QwenImageEditPipeline(H.FluxKontextPipeline):
     """Vanilla loop: sequential cond / uncond forwards + norm-preserving CFG (inplace.py:371-405)."""
 
-    def _shapes(self, height, width):
+    def _shapes(self, height, width, cond_shapes=None):
+        """img_shapes of the forward (QwenImageEdit/inplace.py:272-277): the noise grid, then one (1, h_tok, w_tok) per
+        condition image - several for Qwen-Image-Edit-2509 (QwenImageEditPlus/inplace.py:293-300); default: one, same size."""
         s = (1, height // self.vae_scale_factor // 2, width // self.vae_scale_factor // 2)
-        return [[s, s]]
+        if cond_shapes is None:
+            return [[s, s]]
+        return [[s] + [(1, int(h), int(w)) for h, w in cond_shapes]]
 
-    def prepare_qwen(self, image, height, width, latents, generator, num_inference_steps):
+    def prepare_qwen(self, image, height, width, latents, generator, num_inference_steps, cond_shapes=None):
+        """`image`: packed condition latents [1, L_c, 64], or a list of them (one per condition image, in order)."""
+        if isinstance(image, (list, tuple)):
+            if cond_shapes is not None:
+                assert [int(h) * int(w) for h, w in cond_shapes] == [x.shape[1] for x in image], "cond_shapes vs latents"
+            image = torch.cat(list(image), dim=1)
+        if cond_shapes is not None:
+            assert sum(int(h) * int(w) for h, w in cond_shapes) == image.shape[1], "cond_shapes do not cover the condition latents"
         dummy = torch.zeros(1, 1, 1)
         latents, image_latents, _, _, h_tok, w_tok = self.prepare(image, dummy, None, height, width, latents, generator,
                                                                   num_inference_steps)
@@ -117,10 +128,11 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, negative_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, true_cfg_scale=4.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True):
-        latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps)
+                 return_dict=True, cond_shapes=None):
+        latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps,
+                                                               cond_shapes)
         timesteps = self.scheduler.timesteps
-        img_shapes = self._shapes(height, width)
+        img_shapes = self._shapes(height, width, cond_shapes)
         do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None
         self.scheduler.set_begin_index(0)
         self._precompute(timesteps, None, latents.dtype)
@@ -146,5 +158,6 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
 
 
 class QwenImageEditPlusPipeline(QwenImageEditPipeline):
-    """Qwen-Image-Edit-2509: same kernels; multi-image conditioning is list handling in front of the hot
-    path (QwenImageEditPlus/inplace.py:229-299) - the harness takes the concatenated condition latents."""
+    """Qwen-Image-Edit-2509: same kernels; multi-image conditioning (QwenImageEditPlus/inplace.py:229-299) = a LIST of
+    packed condition latents + `cond_shapes` [(h_tok, w_tok), ...]: one rotary frame index per image, keys / values over
+    T + L + sum(L_c) rows."""

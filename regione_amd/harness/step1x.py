@@ -36,7 +36,17 @@ class Step1XEditTransformer2DModel(H.FluxTransformer2DModel):
         self._vec = dict(y_rows) if isinstance(y_rows, dict) else list(y_rows)
 
     def connector(self, encoder_hidden_states, timestep, prompt_embeds_mask):
+        """[EXT] hook of the Qwen2 connector (Step1XEdit/inplace.py:514-516).  Latent-level default: the caller already
+        passed the connector's OUTPUTS.  A hosted pipeline (regione_amd.adapters) installs the host transformer's real
+        connector here as an instance attribute; it is then called once per computed step, like the reference does."""
         return encoder_hidden_states, self._vec
+
+    def branch_inputs(self, encoder_hidden_states, y, timestep, tag):
+        """Sequential-CFG form of the same hook (v1p2: one forward per branch `tag`)."""
+        c = self.__dict__.get("connector")
+        if c is None:
+            return encoder_hidden_states, y
+        return c(encoder_hidden_states, timestep, None, tag=tag)
 
     def forward(self, hidden_states, encoder_hidden_states=None, prompt_embeds_mask=None, timestep=None, img_ids=None,
                 txt_ids=None, guidance=None, joint_attention_kwargs=None, return_dict=True):
@@ -123,6 +133,7 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             def branch(pe, y, ids_t, tag):
                 rope = tr.pos_embed(torch.cat((ids_t, latent_ids), dim=0), tr.device)
+                pe, y = tr.branch_inputs(pe, y, timestep / 1000, tag)
                 return tr._run(x, pe, y, timestep / 1000, None, rope, False, {"tag": tag},
                                out_rows=latents.size(1))[0][:, : latents.size(1)]
             outs = D.run_cfg_branches(getattr(self, "_cfg_pair", None),

@@ -43,10 +43,25 @@ def resample_gamma(table, num_inference_steps: int):
 
 class RegionEHelper(object):
     def __init__(self, pipeline=None):
+        # Three kinds of `pipeline`:
+        #   * a regione_amd.harness pipeline (latent-level, HIP transformer): patched directly;
+        #   * a STOCK diffusers pipeline object (the reference's case, RegionE/README.md:85-113): its transformer weights are
+        #     adopted onto the HIP engine once (regione_amd.adapters.attach, kept at pipeline._regione_engine), the patch set
+        #     goes on that engine, and enable() swaps pipeline.__class__ so the user keeps calling pipeline(image=, prompt=);
+        #   * a regione_amd.adapters.HostedPipeline wrapper (host + engine): the patch set goes on its engine.
+        self.host = None
         if pipeline is not None:
-            # a hosted pipeline (regione_amd.adapters.adopt) keeps the host for pre / post; the patch set goes on its engine
-            self.pipeline = getattr(pipeline, "_regione_engine", pipeline)
+            from .. import adapters
+            if not adapters.is_engine_pipeline(pipeline) and not isinstance(pipeline, adapters.HostedPipeline):
+                if adapters._host_name(pipeline) not in config:
+                    raise KeyError(f"RegionE has no patch set for pipeline class {pipeline.__class__.__name__}")
+                self.host = pipeline
+                self.pipeline = adapters.attach(pipeline)
+            else:
+                self.pipeline = getattr(pipeline, "_regione_engine", pipeline)
         self.name = self.pipeline.__class__.__name__
+        if self.name.startswith("RegionE") and getattr(self.pipeline, "_regione_vanilla_class", None) is not None:
+            self.name = self.pipeline._regione_vanilla_class.__name__        # a second helper on an enabled pipeline
         # per-helper copy: the reference mutates the module-level dict in set_params (RegionE.py:43-51),
         # which leaks settings between helpers; same defaults, no leak.
         self.config = copy.deepcopy(config[self.name])
@@ -60,10 +75,16 @@ class RegionEHelper(object):
     def enable(self):
         assert self.pipeline is not None
         self.pipeline = self._family().warp_modules(self.pipeline, **self.config)
+        if self.host is not None:
+            from .. import adapters
+            adapters.swap_host_class(self.host)          # hook (1) on the user's own pipeline object
 
     def disable(self):
         assert self.pipeline is not None
         self.pipeline = self._family().unwarp_modules(self.pipeline)
+        if self.host is not None:
+            from .. import adapters
+            adapters.restore_host_class(self.host)
 
     def shard_cfg_branches(self, pair):
         """Extension: run the 'cond' and 'uncond' forwards of one image on the two ranks of

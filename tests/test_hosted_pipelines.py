@@ -1,0 +1,160 @@
+"""-m gpu: the reference's CALL SHAPE on a stock pipeline object (RegionE/README.md:85-113, tool/RegionE.py:9-27):
+
+    helper = RegionEHelper(pipe); helper.set_params(...); helper.enable()
+    image = pipe(image=..., prompt=...)            # the user keeps calling the pipeline itself
+    helper.disable()
+
+for all five pipeline classes, against host stand-ins with the method surface the reference's patched `__call__`s use
+(tests/host_standins.py; diffusers itself is not installable here).  Checked: the class swap and its undo, the host
+methods called in the reference's order, the loop == the engine's latent-level call on the same inputs (bit for bit
+where the text path is static), Step1X's connector driven once per computed forward, Qwen-Image-Edit-2509 with a LIST of
+condition images, the per-stage wall-clock fields.
+"""
+import pytest
+import torch
+
+from regione_amd import RegionEHelper, adapters as A
+
+import host_standins as HS
+
+pytestmark = pytest.mark.gpu
+
+
+def _picture(h=256, w=256, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.rand(1, 3, h, w, generator=g)
+    p[:, :, h // 4: h // 4 + h // 3, w // 3: w // 3 + w // 3] = 0.0
+    return p
+
+
+def _gen():
+    return torch.Generator().manual_seed(1)
+
+
+def test_flux_stock_pipeline_call_shape():
+    pipe = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
+    cls = type(pipe)
+    helper = RegionEHelper(pipe)                                 # weights adopted here (pipe._regione_engine)
+    assert helper.name == "FluxKontextPipeline" and A.is_engine_pipeline(helper.pipeline) and not A.is_engine_pipeline(pipe)
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    assert type(pipe).__name__ == "RegionEFluxKontextPipeline" and isinstance(pipe, cls)
+    trace = {}
+    out = pipe(image=_picture(), prompt="make the square red", generator=_gen(), output_type="pt", guidance_scale=2.5,
+               preferred_resolutions=[(256, 256)], trace=trace)
+    assert tuple(out.images.shape) == (1, 3, 256, 256) and torch.isfinite(out.images).all()
+    assert [c[0] for c in pipe.calls] == ["encode_prompt", "prepare_latents", "unpack", "free"]
+    assert len(trace["kind"]) == 28 and "".join(trace["kind"]).startswith("FFFFFF") and "R" in trace["kind"]
+    assert set(out.timing) == {"encode_s", "loop_s", "decode_s"} and all(v >= 0 for v in out.timing.values())
+    # default auto-resize snaps to a Kontext training resolution (advisor finding: the table is the DEFAULT)
+    assert (1024, 1024) in A.PREFERRED_KONTEXT_RESOLUTIONS and len(A.PREFERRED_KONTEXT_RESOLUTIONS) == 17
+    # the loop the patched pipeline ran == the patched engine's latent-level call on the same packed inputs
+    lat = pipe(image=_picture(), prompt="make the square red", generator=_gen(), output_type="latent", guidance_scale=2.5,
+               preferred_resolutions=[(256, 256)]).images
+    pe, pp, _ = pipe.encode_prompt(prompt="make the square red")
+    l0, il, _, _ = pipe.prepare_latents(_picture() * 2 - 1, 1, 16, 256, 256, torch.bfloat16, None, _gen())
+    direct = helper.pipeline(image=il.cuda(), prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(), height=256, width=256,
+                             latents=l0.cuda(), guidance_scale=2.5, return_dict=False)[0]
+    assert torch.equal(lat, direct)
+    helper.disable()
+    assert type(pipe) is cls and getattr(pipe, "_regione_host_class", None) is None
+    # a second helper re-uses the adopted engine instead of copying 12 B parameters again
+    assert RegionEHelper(pipe).pipeline is helper.pipeline
+    with pytest.raises(KeyError):
+        RegionEHelper(type("StableDiffusionPipeline", (), {"transformer": None})())
+
+
+@pytest.mark.parametrize("v1p2", [False, True])
+def test_step1x_stock_pipeline_call_shape_with_host_connector(v1p2):
+    cls = HS.Step1XEditPipelineV1P2 if v1p2 else HS.Step1XEditPipeline
+    trunk = HS.stub_trunk("step1x")
+    pipe = cls(trunk)
+    conn = HS.ToyConnector().to(torch.bfloat16)
+    object.__setattr__(trunk, "connector", conn)                 # the host's own text path (timestep dependent)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    assert type(pipe).__name__ == "RegionE" + cls.__name__
+    trace = {}
+    kw = dict(image=_picture(), prompt="turn the sky green", generator=_gen(), output_type="latent", trace=trace)
+    if not v1p2:
+        kw["latents"] = None
+    a = pipe(**kw).images
+    kinds = "".join(trace["kind"])
+    assert len(kinds) == 28 and torch.isfinite(a.float()).all() and a.shape == (1, 256, 64)
+    names = [c[0] for c in pipe.calls]
+    assert names[:4] == ["encode_image", "encode_prompt", "encode_prompt", "prepare_latents"]
+    assert pipe.calls[0][1] == (3 if v1p2 else 2)                # v1p2's encode_image takes size_level
+    assert pipe.calls[2][1] == ""                                # no negative prompt given + an image -> "" (inplace.py:231)
+    # the connector ran once per branch per COMPUTED forward, never on cache-served steps
+    computed = kinds.count("F") + kinds.count("R")
+    assert conn.calls == 2 * computed and kinds.count("C") > 0
+    assert "connector" not in helper.pipeline.transformer.__dict__          # hook removed after the call
+    # deterministic; image-space output goes through the host's decode + _output_process_image
+    conn.calls = 0
+    kw["generator"] = _gen()
+    b = pipe(**kw).images
+    assert torch.equal(a, b)
+    kw.update(output_type="pt", generator=_gen())
+    img = pipe(**kw)
+    assert tuple(img.images.shape) == (1, 3, 256, 256) and ("output_process", (256, 256)) in pipe.calls
+    helper.disable()
+    assert type(pipe) is cls
+
+
+def test_qwen_stock_pipeline_call_shape():
+    pipe = HS.QwenImageEditPipeline(HS.stub_trunk("qwen"))
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    trace = {}
+    kw = dict(image=_picture(), prompt="add a hat", negative_prompt=" ", true_cfg_scale=4.0, height=256, width=256,
+              generator=_gen(), output_type="latent")
+    lat = pipe(trace=trace, **kw).images
+    assert lat.shape == (1, 256, 64) and torch.isfinite(lat.float()).all() and len(trace["kind"]) == 28
+    assert [c[0] for c in pipe.calls[:3]] == ["encode_prompt", "encode_prompt", "prepare_latents"]
+    # == the engine's latent-level call: the condition image is resized to the 1024^2-area grid (calculate_dimensions), so
+    # L_c = 4096 tokens against L = 256 -> the reference's own partition would fail here (shape mismatch); ours requires the
+    # LAST condition image to have the output grid, so run the comparison on the vanilla loop
+    helper.disable()
+    van = pipe.__class__
+    hosted = A.adopt(pipe)
+    with pytest.raises(AssertionError, match="output token grid"):
+        RegionEHelper(hosted).enable() or hosted(trace={}, **kw)
+    RegionEHelper(hosted).disable()
+    lat_v = hosted(**kw).images
+    pe, _ = pipe.encode_prompt(prompt="add a hat")
+    ne, _ = pipe.encode_prompt(prompt=" ")
+    img = pipe.image_processor.preprocess(pipe.image_processor.resize(_picture(), 1024, 1024), 1024, 1024).unsqueeze(2)
+    l0, il = pipe.prepare_latents(img, 1, 16, 256, 256, torch.bfloat16, None, _gen())
+    direct = hosted.engine(image=il.cuda(), prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), height=256, width=256,
+                           latents=l0.cuda(), true_cfg_scale=4.0, return_dict=False, cond_shapes=[(64, 64)])[0]
+    assert torch.equal(lat_v, direct)
+    assert type(pipe) is van
+
+
+def test_qwen_plus_list_of_condition_images():
+    """Qwen-Image-Edit-2509: two condition images of different aspect ratios; each is resized for the VLM (384^2 area) and
+    for the VAE (1024^2 area); the LAST one fixes the output size and is the partition's reference image."""
+    pipe = HS.QwenImageEditPlusPipeline(HS.stub_trunk("qwen"))
+    helper = RegionEHelper(pipe)
+    assert helper.name == "QwenImageEditPlusPipeline"
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    trace = {}
+    images = [_picture(192, 384, seed=2), _picture(256, 256, seed=3)]
+    out = pipe(image=images, prompt="put the object of image 1 into image 2", negative_prompt=" ", true_cfg_scale=4.0,
+               generator=_gen(), output_type="latent", trace=trace).images
+    L = 64 * 64                                                    # last image 1:1 -> 1024 x 1024 -> 64 x 64 tokens
+    assert out.shape == (1, L, 64) and torch.isfinite(out.float()).all() and len(trace["kind"]) == 28
+    assert pipe.calls[0] == ("encode_prompt", "put the object of image 1 into image 2", 2)
+    eng = helper.pipeline
+    M = eng._regione_manager
+    # first image 2:1 -> calculate_dimensions(1024^2, 2) = 1440 x 736 -> 46 x 90 tokens; K/V rows = T + L + both images
+    n1 = (736 // 16) * (1440 // 16)
+    assert M.latent_ids.shape[0] == L + n1 + L
+    proc = eng.transformer.transformer_blocks[0].attn.processor
+    T = pipe.encode_prompt(prompt="put the object of image 1 into image 2")[0].shape[1]
+    assert proc.caches["cond"][2] == T + L + n1 + L
+    assert M.condition_latent.shape[1] == L and 0 < M.edited_ids.shape[1] < L
+    helper.disable()

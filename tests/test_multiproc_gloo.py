@@ -65,6 +65,14 @@ def test_image_sharding_ragged_batch():
     assert all(r[2] for r in res)
 
 
+def test_image_sharding_fewer_images_than_ranks():
+    """n_images < world: rank 1 owns nothing - it must still take part in the gather (advisor finding, round 1: it used to
+    index local[0] and die while rank 0 sat in all_gather)."""
+    res = _run(1)
+    assert res[0][1] == [0] and res[1][1] == []
+    assert all(r[2] for r in res)
+
+
 def test_shard_images_partition():
     from regione_amd import dist as D
     for n in (0, 1, 5, 8, 17):
