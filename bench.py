@@ -115,6 +115,8 @@ class KernelTimer:
             r = timer._orig_attn(q, k_slab, vt_slab, out, skv, H, scale)
             e.record()
             timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * H * 128))
+            if q.shape[0] < skv:             # region step: the K / V^T cache slabs are streamed once per launch
+                timer.rec.setdefault("_region_attention_kv", []).append((s, e, 2.0 * skv * H * 128 * 2))
             return r
 
         ops.gemm, ops.attention, ops.gemm_pair = gemm, attention, gemm_pair
@@ -128,11 +130,49 @@ class KernelTimer:
     def summary(self):
         out = {}
         for name, lst in self.rec.items():
+            if name.startswith("_"):
+                continue
             ms = sum(s.elapsed_time(e) for s, e, _ in lst)
             fl = sum(f for _, _, f in lst)
             out[name] = dict(launches=len(lst), total_ms=ms, avg_us=1e3 * ms / len(lst), flops_per_launch=fl / len(lst),
                              achieved_tflops=fl / (ms * 1e-3) / 1e12)
         return out
+
+    def region_kv_read(self):
+        """"KV-read HBM GB/s in region attention" - algorithmic K + V^T slab bytes of the region-step attention
+        launches / their time (the launches are MFMA-bound at K_e = 25 %: this is the rate the cache is consumed at, not a
+        bandwidth ceiling)."""
+        lst = self.rec.get("_region_attention_kv", [])
+        if not lst:
+            return None
+        ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+        return dict(launches=len(lst), bytes_per_launch=lst[0][2], avg_launch_us=1e3 * ms / len(lst),
+                    achieved_gbs=sum(b for _, _, b in lst) / (ms * 1e-3) / 1e9, peak_gbs=8000.0)
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) of the host from /proc/cpuinfo."""
+    logical, pairs, phys = os.cpu_count() or 1, set(), None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((phys, line.split(":")[1].strip()))
+    except OSError:
+        pass
+    return (len(pairs) or logical), logical
+
+
+def csrc_hash():
+    """sha256 of the kernel sources: stamps the PMC files so that bench.py only quotes traffic measured on THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "regione_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_pipeline(cfg, device, seed):
@@ -182,7 +222,8 @@ def cpu_baseline(cfg, T, N, K_e, plan):
     extrapolated x layer counts x the F/R/C plan to steps/s."""
     from oracle import regione_oracle as O
     from regione_amd import synth
-    torch.set_num_threads(os.cpu_count())
+    phys, logical = physical_cores()
+    torch.set_num_threads(phys)
     one = synth.FluxConfig(in_channels=cfg.in_channels, n_double=1, n_single=1, heads=cfg.heads, head_dim=cfg.head_dim,
                            joint_dim=cfg.joint_dim, pooled_dim=cfg.pooled_dim)
     w = synth.make_flux_weights(one, seed=1, dtype=torch.float32)
@@ -232,8 +273,8 @@ def cpu_baseline(cfg, T, N, K_e, plan):
                 break
     except OSError:
         pass
-    return dict(value=N_STEPS / edit_s, unit="steps/s", cores=os.cpu_count(), kind="port",
-                sample=(f"oracle (torch-CPU eager fp32, {os.cpu_count()} threads, {cpu_model}): 1 double + 1 single block at "
+    return dict(value=N_STEPS / edit_s, unit="steps/s", cores=phys, logical_cpus=logical, kind="port",
+                sample=(f"oracle (torch-CPU eager fp32, {phys} threads = physical cores, {cpu_model}): 1 double + 1 single block at "
                         f"FULL ({T}+{N} rows) timed once, 1 single block at REGION ({T}+{K_e} query rows) timed once (double-block REGION "
                         f"time scaled by the FULL ratio) = {times['double_full'] + times['single_full'] + times['single_region']:.1f} s of CPU "
                         f"work, extrapolated x{cfg.n_double}/{cfg.n_single} layers x plan {n_full}F/{n_reg}R/"
@@ -248,6 +289,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up edits")
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--edit-frac", type=float, default=0.25)
+    ap.add_argument("--edit-fracs", default="0.05,0.15,0.25,0.50",
+                    help="N > 1: rank r edits fraction fracs[r %% len] of its image (SURVEY.md section 8e: the only scaling loss the "
+                         "path has is K_e imbalance between images); N = 1 uses --edit-frac")
+    ap.add_argument("--uniform-edit-frac", action="store_true", help="N > 1: every rank uses --edit-frac")
+    ap.add_argument("--true-cfg", type=float, default=0.0,
+                    help="true CFG scale (> 1: a cond and an uncond forward per computed step, one K/V cache per branch): "
+                         "`--gpus 8 --true-cfg 6.0` is BASELINE.json configs[3]")
     ap.add_argument("--toy", action="store_true", help="toy model (debugging only; result is not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vanilla", action="store_true")
@@ -277,7 +325,11 @@ def main():
     h_tok = w_tok = args.size // 16
     L = h_tok * w_tok
     N = 2 * L
-    side = int(round((args.edit_frac * L) ** 0.5))
+    edit_frac = args.edit_frac
+    if world > 1 and not args.uniform_edit_frac:
+        fr = [float(x) for x in args.edit_fracs.split(",")]
+        edit_frac = fr[rank % len(fr)]
+    side = int(round((edit_frac * L) ** 0.5))
     box_side = max(side - 2, 3)                      # erosion -1 ring, dilation +2 rings -> side x side
     r0 = (h_tok - box_side) // 2
     box = (r0, r0 + box_side, r0, r0 + box_side)
@@ -288,6 +340,11 @@ def main():
     t_build = time.perf_counter() - t_build
     lat, img, prompt, pooled = synth.make_edit_inputs(h_tok, w_tok, T, cfg, seed=110 + rank, dtype=torch.bfloat16)
     lat, img, prompt, pooled = lat.to(device), img.to(device), prompt.to(device), pooled.to(device)
+    cfg_kw = {}
+    if args.true_cfg > 1:
+        _, _, nprompt, npooled = synth.make_edit_inputs(h_tok, w_tok, T, cfg, seed=910 + rank, dtype=torch.bfloat16)
+        cfg_kw = dict(true_cfg_scale=args.true_cfg, negative_prompt_embeds=nprompt.to(device),
+                      negative_pooled_prompt_embeds=npooled.to(device))
 
     helper = RegionEHelper(pipe)
     import contextlib
@@ -298,7 +355,9 @@ def main():
 
     def edit(trace=None):
         return pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=args.size, width=args.size,
-                    latents=lat, guidance_scale=2.5, return_dict=False, trace=trace)[0]
+                    latents=lat, guidance_scale=2.5, return_dict=False, trace=trace, **cfg_kw)[0]
+
+    rank_edit_s = []
 
     for _ in range(args.warmup):
         out = edit()
@@ -313,7 +372,13 @@ def main():
             instrument = (k == args.steps - 1) and not os.environ.get("RGN_BENCH_NO_KTIMER")
             if instrument:
                 timer.wrap(ops)
+            if world > 1:
+                torch.cuda.synchronize()
+                t_e = time.perf_counter()
             o = edit()
+            if world > 1:                    # this rank's own edit time (the collective below waits for the slowest rank)
+                torch.cuda.synchronize()
+                rank_edit_s.append(time.perf_counter() - t_e)
             if instrument:
                 timer.unwrap()
             # every rank ends with every image's final latents (512 KB each): the only data collective
@@ -328,35 +393,51 @@ def main():
     K_e = int(pipe._regione_manager.edited_ids.shape[1])
     f_full, f_reg = algorithmic_flops(cfg, T, N, K_e)
     n_full, n_reg, n_cache = kinds.count("F"), kinds.count("R"), kinds.count("C")
-    flops_edit = n_full * f_full + n_reg * f_reg
+    flops_edit = (n_full * f_full + n_reg * f_reg) * (2 if args.true_cfg > 1 else 1)
+    per_rank = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, dict(rank=rank, K_e=K_e, edit_frac=edit_frac,
+                                              edit_s=sum(rank_edit_s) / max(len(rank_edit_s), 1)))
     edit_s = elapsed / args.steps
     ksum = timer.summary()
 
     result = {
         "metric": "denoising steps/sec (28-step RegionE edit, 1024x1024)", "value": N_STEPS * args.steps * world / elapsed,
         "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * edit_s,
+        "step_definition": "one bench step = one complete 28-step edit of one image per GPU (ms_per_step = ms per EDIT; "
+                           "ms_per_denoising_step = ms_per_step / 28)",
+        "ms_per_denoising_step": 1e3 * edit_s / N_STEPS,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"FLUX.1-Kontext-dev {args.size}x{args.size} 28-step RegionE edit, warmup=6 post=2 refresh=16 "
                                f"thresh=0.88 cache_thresh=0.04, L=L_c={L}, T={T}, K_e={K_e} ({100.0 * K_e / L:.1f}% edited by "
-                               f"construction), plan {kinds}", "images_per_gpu": 1, "parallelism": f"image-sharded x{world}",
+                               f"construction), plan {kinds}" + (f", true CFG {args.true_cfg} (two forwards per computed step)"
+                                                                  if args.true_cfg > 1 else ""),
+                   "images_per_gpu": 1, "parallelism": f"image-sharded x{world}",
                    "params_billion": round(sum(int(torch.tensor(s).prod()) for s in synth.flux_param_shapes(cfg).values()) / 1e9, 2)},
         "edit_wall_clock_s": edit_s,
         "algorithmic_tflop_per_edit": flops_edit / 1e12,
         "loop_mfma_frac": flops_edit / edit_s / 1e12 / PEAK_BF16_TFLOPS,
         "model_build_s": t_build,
     }
-    pmc = {}
-    try:    # PMC passes cannot run inside the timed region: the per-launch HBM-side traffic comes from the committed
-        # rocprofv3 --pmc passes of this same command (profiles/r01_pmc_traffic.json, see its "note")
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    if per_rank is not None:
+        result["per_rank"] = per_rank          # K_e imbalance between images = the path's only scaling loss
+    # PMC passes cannot run inside the timed region (counter collection serialises kernels): the per-launch HBM-side
+    # traffic comes from a separate rocprofv3 --pmc run of THIS command (tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json),
+    # quoted only when that file was measured on the same kernel sources (csrc_sha16); otherwise null
+    pmc, pmc_file = {}, "profiles/r02_pmc_traffic.json"
+    try:
+        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+        if pmc.get("csrc_sha16") != csrc_hash():
+            pmc = {}
     except (OSError, ValueError):
-        pass
+        pmc = {}
     if "gemm_bf16_kernel" in ksum:
         k = ksum["gemm_bf16_kernel"]
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": k["achieved_tflops"],
                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
                               "traffic": pmc.get("gemm_bf16_kernel", {}).get("traffic_bytes_per_launch"),
-                              "traffic_unit": "bytes/launch (L2->fabric reads x2-corrected + WRITE_SIZE, profiles/r01_pmc_traffic.json)",
+                              "traffic_unit": f"bytes/launch (L2<-fabric reads x2-corrected + WRITE_SIZE, {pmc_file}, same csrc_sha16)",
                               "launches": k["launches"], "avg_launch_us": k["avg_us"],
                               "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
     result["gemm_shapes"] = timer.shape_table()
@@ -368,6 +449,9 @@ def main():
                                         "launches": k["launches"], "avg_launch_us": k["avg_us"],
                                         "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
 
+    kv = timer.region_kv_read()
+    if kv is not None:
+        result["region_attention_kv_read"] = kv
     if rank == 0 and world == 1 and not args.no_vanilla:
         # full-token denoising on the same engine: the speed-up the reference headlines (README.md:23)
         helper.disable()

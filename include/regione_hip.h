@@ -167,6 +167,30 @@ int rgn_gemm_bf16_qkv_pair(const void* A0, int lda0, const void* W0, const void*
                            void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* fp8 weights (BASELINE.json configs[4]: "fp8 weights on CDNA4").  The same four GEMM entry points with W stored as OCP
+ * e4m3fn bytes ([N, K], ldw in BYTES, a multiple of 16) plus one fp32 scale per output channel (`wscale[N]`, 16-byte
+ * aligned): C = epilogue((A @ dequant(W8)^T) * wscale[n] + bias).  Activations, bias, outputs and every epilogue stay
+ * bf16 / fp32 exactly as in the bf16 calls; the fp8 -> bf16 conversion is exact (v_cvt_scalef32_pk_bf16_fp8 in registers, after
+ * the LDS read), the scale multiplies the fp32 accumulator.  Replaces nothing in the reference (which ships bf16 weights):
+ * storage format of the [EXT] Linear weights only; quantisation (per-channel absmax / 448) is done by the caller
+ * (regione_amd.harness.flux.FluxTransformer2DModel.quantize_fp8_). */
+int rgn_gemm_w8(const void* A, int lda, const void* W8, int ldw, const float* wscale, const void* bias, void* C, int ldc,
+                int M, int N, int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
+                const int64_t* out_rows, void* workspace, size_t workspace_bytes, void* stream);
+int rgn_gemm_w8_pair(const void* A0, int lda0, const void* W0, const float* wscale0, const void* bias0, void* C0, int ldc0,
+                     int M0, const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1,
+                     const float* wscale1, const void* bias1, void* C1, int ldc1, int M1, const void* gate1,
+                     const void* resid1, int N, int K, int epilogue, int gelu_from_col, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int rgn_gemm_w8_qkv(const void* A, int lda, const void* W8, int ldw, const float* wscale, const void* bias, void* C, int ldc,
+                    int M, int N, int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int rgn_gemm_w8_qkv_pair(const void* A0, int lda0, const void* W0, const float* wscale0, const void* bias0, void* C0,
+                         int ldc0, int M0, const rgn_qkv_epilogue* e0, const void* A1, int lda1, const void* W1,
+                         const float* wscale1, const void* bias1, void* C1, int ldc1, int M1,
+                         const rgn_qkv_epilogue* e1, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
+
+
 /* Skinny GEMV for the AdaLN modulation / timestep embedders:
  *   y[b,n] = bf16( sum_k W[n,k] * act(x[b,k]) + bias[n] ),  act = silu (rounded to bf16) if silu_input.
  * B <= 4, K % 8 == 0.  HBM-bound on W. */

@@ -58,6 +58,17 @@ SIGNATURES = {
     "rgn_gemm_bf16_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                            _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
                            _c_int, _c_int, _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],
+    # fp8 (e4m3fn) weights + per-output-channel fp32 scales: the bf16 signatures with a scale pointer behind each W
+    "rgn_gemm_w8": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                    _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_gemm_w8_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
+                         _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p,
+                         _c_int, _c_int, _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_gemm_w8_qkv": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                        _c_int, _qkv_p, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_gemm_w8_qkv_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _qkv_p,
+                             _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _qkv_p,
+                             _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_void_p],
     "rgn_rms_norm_rows": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p],

@@ -291,7 +291,7 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
                    timesteps_truncate: float = 0.93, process_norm_power: float = 0.4, size_level=None, trace=None, **unused):
     """Step1XEditPipeline / Step1XEditPipelineV1P2 `__call__` around the engine loop (Step1XEdit/inplace.py:185-330,:437-455;
     Step1XEditV1P2/inplace.py:214-300).  Not hosted: v1p2's thinking / reflection retry loop (VLM prompting, :192-212)."""
-    v1p2 = type(eng).__name__.endswith("V1P2")
+    v1p2 = _host_name(host).endswith("V1P2")
     dev = eng.transformer.device
     clk = _Clock(dev)
     exec_dev = getattr(host, "_execution_device", dev)
@@ -371,7 +371,7 @@ def _hosted_qwen(host, eng, image=None, prompt=None, negative_prompt=None, true_
     """QwenImageEditPipeline / QwenImageEditPlusPipeline `__call__` around the engine loop (QwenImageEdit/inplace.py:180-330,
     :434-455; QwenImageEditPlus/inplace.py:189-300: a LIST of condition images, each resized twice - 384^2 area for the VLM,
     1024^2 area for the VAE - the last one fixing the output size)."""
-    plus = "Plus" in type(eng).__name__
+    plus = "Plus" in _host_name(host)
     dev = eng.transformer.device
     clk = _Clock(dev)
     exec_dev = getattr(host, "_execution_device", dev)

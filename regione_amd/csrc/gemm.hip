@@ -58,6 +58,7 @@ struct GemmArgs {
     int lda, ldw, ldc;
     int M, N, K;
     int gelu_from_col;
+    const float* wscale;         // fp8 (OCP e4m3) weights: per-output-channel scale, applied to the fp32 accumulator; else nullptr
 };
 
 constexpr int BK = 64;
@@ -189,8 +190,13 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;        // 16x16 MFMA tiles per wave
     constexpr bool ASM4W = (BM == 256 && BN == 256 && WM == 2 && WN == 2);
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;          // 1 KiB DMA pieces per wave per stage
+    // AV == 8: W is fp8 (OCP e4m3fn), one byte per element: its LDS tile has 64-byte rows, a 1 KiB DMA piece covers 16 rows,
+    // a fragment is one ds_read_b64 (8 values) converted to bf16 in registers (v_cvt_scalef32_pk_bf16_fp8, exact); the
+    // per-output-channel scale multiplies the fp32 accumulator in the epilogue.  Half the weight bytes from HBM / L2.
+    constexpr bool W8 = (AV == 8);
+    static_assert(!(W8 && ASM4W), "fp8 weights run on the compiler-scheduled geometries");
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = W8 ? BN * BK : BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int PA = BM / 8 / NW, PB = (W8 ? BN / 16 : BN / 8) / NW;          // 1 KiB DMA pieces per wave per stage
     constexpr int CT_LD = BN + 8;                              // padded bf16 row of the C staging tile
     // C rows staged per epilogue chunk: one wave row at a time (the staging tile then fits inside the K-loop
     // stages), except for the fused Q/K/V epilogue, which stages the whole tile at once so that no wave keeps its
@@ -241,8 +247,16 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
     }
 #pragma unroll
     for (int q = 0; q < PB; ++q) {
-        const int br = min(n0 + (wave * PB + q) * 8 + srow, g.N - 1);
-        b_src[q] = (const uint8_t*)(g.W + (size_t)br * g.ldw) + schunk * 16;
+        if constexpr (W8) {
+            // 16 rows x 64 bytes per piece: lane -> (row lane>>2, 16-byte chunk lane&3); bank swizzle: the 8-byte slot index
+            // ^= ((row >> 2) & 3) << 1, i.e. the 16-byte chunk ^= (row >> 2) & 3 - applied on the source, like the bf16 tiles
+            const int r16 = lane >> 2;
+            const int br = min(n0 + (wave * PB + q) * 16 + r16, g.N - 1);
+            b_src[q] = (const uint8_t*)g.W + (size_t)br * g.ldw + (((lane & 3) ^ ((r16 >> 2) & 3)) * 16);
+        } else {
+            const int br = min(n0 + (wave * PB + q) * 8 + srow, g.N - 1);
+            b_src[q] = (const uint8_t*)(g.W + (size_t)br * g.ldw) + schunk * 16;
+        }
     }
     auto stage = [&](int kt, int buf) {
         uint8_t* base = smem + buf * STAGE;
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                                              (lds_ptr_t)(base + (wave * PA + q) * 1024), 16, 0, 0);
 #pragma unroll
         for (int q = 0; q < PB; ++q)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(b_src[q] + (size_t)kt * (BK * 2)),
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(b_src[q] + (size_t)kt * (W8 ? BK : BK * 2)),
                                              (lds_ptr_t)(base + A_BYTES + (wave * PB + q) * 1024), 16, 0, 0);
     };
 
@@ -263,7 +277,8 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
     for (int kk = 0; kk < 2; ++kk) {
         const int slot = (kk * 4 + fk) ^ (frow & 7);
         a_off[kk] = (wm * (BM / WM) + frow) * 128 + slot * 16;
-        b_off[kk] = A_BYTES + (wn * (BN / WN) + frow) * 128 + slot * 16;
+        if constexpr (W8) b_off[kk] = A_BYTES + (wn * (BN / WN) + frow) * 64 + (((kk * 4 + fk) ^ (((frow >> 2) & 3) << 1)) * 8);
+        else b_off[kk] = A_BYTES + (wn * (BN / WN) + frow) * 128 + slot * 16;
     }
 
     f32x4 acc[TM][TN];
@@ -361,7 +376,18 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
             for (int kk = 0; kk < 2; ++kk) {
                 bf8_t af[TM], bfr[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (W8) {
+                        const uint2 raw = *(const uint2*)(sb + b_off[kk] + j * 1024);        // 8 fp8 values of one row
+                        const bf2_t c0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, false);
+                        const bf2_t c1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.x, 1.0f, true);
+                        const bf2_t c2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, false);
+                        const bf2_t c3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(raw.y, 1.0f, true);
+                        bfr[j] = bf8_t{c0[0], c0[1], c1[0], c1[1], c2[0], c2[1], c3[0], c3[1]};
+                    } else {
+                        bfr[j] = *(const bf8_t*)(sb + b_off[kk] + j * 2048);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i) af[i] = *(const bf8_t*)(sb + a_off[kk] + i * 2048);
 #pragma unroll
@@ -459,9 +485,14 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                 // the bf16 cache (fused_kernels.py:80, quirk A-3): K / V columns of a partial-update problem take the same
                 // fp32 -> fp16 -> bf16 double rounding; every other column rounds once, like F.linear
                 const bool f16rt = (EPI == RGN_EPI_QKV) && g.qkv.fp16_roundtrip && n0 < g.qkv.q_col;
+                float sv[4] = {1.f, 1.f, 1.f, 1.f};
+                if (g.wscale != nullptr) {               // fp8 weights: per-output-channel scale on the fp32 accumulator
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sv[r] = (n0 + nl + r < g.N) ? g.wscale[n0 + nl + r] : 1.f;
+                }
                 auto put = [&](int i, float (&c)[4]) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) c[r] += bv[r];
+                    for (int r = 0; r < 4; ++r) c[r] = c[r] * sv[r] + bv[r];
                     if (f16rt) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) c[r] = (float)(_Float16)c[r];
@@ -687,7 +718,7 @@ template <int BM, int BN, int WM, int WN, int MODE, int AV = 0>
 static int launch_gemm(const GemmGroup& gg, int epilogue, hipStream_t st) {
     constexpr int QKV_TILE = BM * (BN + 8) * 2 + BM * 4;            // whole staged C tile + cache-row table
     constexpr bool ASM4W = (BM == 256 && WM * WN == 4);
-    constexpr int LDS_LOOP = (AV == 1) ? 160 * 1024 : 2 * (BM + BN) * BK * 2;
+    constexpr int LDS_LOOP = (AV == 1) ? 160 * 1024 : (AV == 8) ? 2 * (BM * BK * 2 + BN * BK) : 2 * (BM + BN) * BK * 2;
     constexpr int LDS = (ASM4W && QKV_TILE > LDS_LOOP) ? QKV_TILE : LDS_LOOP;     // the asm variant stages the whole C tile
     constexpr int LDS_QKV = QKV_TILE > LDS ? QKV_TILE : LDS;
     constexpr int NT = 64 * WM * WN;
@@ -802,6 +833,10 @@ static float estimate128(int nt, int K, double flops) {
 // PARTIAL and REDUCE launches must use the SAME geometry: the partial fragments are stored lane-linear)
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_mode(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_t st) {
+    if (gg.p[0].wscale != nullptr) {                  // fp8 weights: compiler-scheduled geometries, AV = 8
+        if constexpr (MODE == MODE_REDUCE) return launch_gemm<BM, BN, WM, WN, MODE>(gg, epilogue, st);   // W is not touched
+        else return launch_gemm<BM, BN, WM, WN, MODE, 8>(gg, epilogue, st);
+    }
     if constexpr (BM == 256 && BN == 256) {
         // RGN_GEMM_ASMV: 0 = two 64 KiB stages, 1 = A ring of two + W ring of three 32 KiB slots (needs >= 4 K tiles)
         static const int asmv = [] { const char* e = getenv("RGN_GEMM_ASMV"); return e ? atoi(e) : 1; }();
@@ -870,6 +905,7 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
         asm4w = asm4w && (size_t)gg.p[i].M * gg.p[i].lda * 2 < ((size_t)1 << 32) && (size_t)gg.p[i].N * gg.p[i].ldw * 2 < ((size_t)1 << 32);
     static const int asm_default = [] { const char* e = getenv("RGN_GEMM_ASM"); return e ? atoi(e) : 1; }();   // RGN_GEMM_ASM=0: A/B switch
     if (!(asm_default || (v && v[0] == '3')) || (v && v[0] == '2')) asm4w = false;
+    if (gg.p[0].wscale != nullptr) asm4w = false;
     const int b = use_big ? 256 : 128;
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
@@ -885,6 +921,7 @@ static void fill(GemmArgs& g, const void* A, int lda, const void* W, int ldw, co
     g.qkv = QkvEpi{};
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.gelu_from_col = (gelu_from_col + 7) & ~7;      // the GELU boundary is honoured per 8-column vector (callers pass multiples of 8)
+    g.wscale = nullptr;
 }
 
 static int fill_qkv(GemmArgs& g, const rgn_qkv_epilogue* e, int N) {
@@ -906,66 +943,144 @@ static int fill_qkv(GemmArgs& g, const rgn_qkv_epilogue* e, int N) {
     return 0;
 }
 
+// fp8 weights (ws0 / ws1 = per-output-channel fp32 scales, nullptr = bf16 weights): W is [N, K] bytes (OCP e4m3fn), ldw in
+// bytes and a multiple of 16
+static int w8_check(const void* W, int ldw, const float* wscale) {
+    if (wscale == nullptr) return 0;
+    if ((ldw % 16) || (((uintptr_t)W | (uintptr_t)wscale) & 15)) return fail(RGN_E_UNSUPPORTED, "gemm_w8: W rows and the scale vector must be 16-byte aligned");
+    return 0;
+}
+
+static int gemm1(const void* A, int lda, const void* W, int ldw, const float* wsc, const void* bias, void* C, int ldc, int M, int N,
+                 int K, int epilogue, int gelu_from_col, const void* gate, const void* resid, const int64_t* out_rows,
+                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (M == 0) return 0;
+    int rc = check_problem(A, lda, W, wsc ? 8 : ldw, C, ldc, M, N, K, epilogue, gate, resid);
+    if (rc || (rc = w8_check(W, ldw, wsc))) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, gate, resid, out_rows);
+    gg.p[0].wscale = wsc;
+    gg.p[1] = gg.p[0];
+    return gemm_dispatch(gg, 1, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static int gemm2(const void* A0, int lda0, const void* W0, const float* ws0, const void* bias0, void* C0, int ldc0, int M0,
+                 const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1, const float* ws1,
+                 const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1, int N, int K,
+                 int epilogue, int gelu_from_col, void* workspace, size_t workspace_bytes, void* stream) {
+    if (M0 == 0 && M1 == 0) return 0;
+    if ((ws0 == nullptr) != (ws1 == nullptr)) return fail(RGN_E_UNSUPPORTED, "gemm pair: both weight matrices must have the same format");
+    if (M0 == 0) return gemm1(A1, lda1, W1, K, ws1, bias1, C1, ldc1, M1, N, K, epilogue, gelu_from_col, gate1, resid1, nullptr, workspace, workspace_bytes, stream);
+    if (M1 == 0) return gemm1(A0, lda0, W0, K, ws0, bias0, C0, ldc0, M0, N, K, epilogue, gelu_from_col, gate0, resid0, nullptr, workspace, workspace_bytes, stream);
+    int rc = check_problem(A0, lda0, W0, ws0 ? 8 : K, C0, ldc0, M0, N, K, epilogue, gate0, resid0);
+    if (rc) return rc;
+    rc = check_problem(A1, lda1, W1, ws1 ? 8 : K, C1, ldc1, M1, N, K, epilogue, gate1, resid1);
+    if (rc || (rc = w8_check(W0, K, ws0)) || (rc = w8_check(W1, K, ws1))) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, gelu_from_col, gate0, resid0, nullptr);
+    fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, gelu_from_col, gate1, resid1, nullptr);
+    gg.p[0].wscale = ws0; gg.p[1].wscale = ws1;
+    return gemm_dispatch(gg, 2, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static int gemm_qkv1(const void* A, int lda, const void* W, int ldw, const float* wsc, const void* bias, void* C, int ldc, int M,
+                     int N, int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+    if (M == 0) return 0;
+    int rc = check_problem(A, lda, W, wsc ? 8 : ldw, C, ldc, M, N, K, RGN_EPI_QKV, nullptr, nullptr);
+    if (rc || (rc = w8_check(W, ldw, wsc))) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, nullptr, nullptr, nullptr);
+    if ((rc = fill_qkv(gg.p[0], e, N))) return rc;
+    gg.p[0].wscale = wsc;
+    gg.p[1] = gg.p[0];
+    return gemm_dispatch(gg, 1, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+static int gemm_qkv2(const void* A0, int lda0, const void* W0, const float* ws0, const void* bias0, void* C0, int ldc0, int M0,
+                     const rgn_qkv_epilogue* e0, const void* A1, int lda1, const void* W1, const float* ws1, const void* bias1,
+                     void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+    if (M0 == 0 && M1 == 0) return 0;
+    if ((ws0 == nullptr) != (ws1 == nullptr)) return fail(RGN_E_UNSUPPORTED, "gemm pair: both weight matrices must have the same format");
+    if (M0 == 0) return gemm_qkv1(A1, lda1, W1, K, ws1, bias1, C1, ldc1, M1, N, K, N, e1, workspace, workspace_bytes, stream);
+    if (M1 == 0) return gemm_qkv1(A0, lda0, W0, K, ws0, bias0, C0, ldc0, M0, N, K, N, e0, workspace, workspace_bytes, stream);
+    int rc = check_problem(A0, lda0, W0, ws0 ? 8 : K, C0, ldc0, M0, N, K, RGN_EPI_QKV, nullptr, nullptr);
+    if (rc) return rc;
+    if ((rc = check_problem(A1, lda1, W1, ws1 ? 8 : K, C1, ldc1, M1, N, K, RGN_EPI_QKV, nullptr, nullptr))) return rc;
+    if ((rc = w8_check(W0, K, ws0)) || (rc = w8_check(W1, K, ws1))) return rc;
+    GemmGroup gg;
+    fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, N, nullptr, nullptr, nullptr);
+    fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, N, nullptr, nullptr, nullptr);
+    if ((rc = fill_qkv(gg.p[0], e0, N))) return rc;
+    if ((rc = fill_qkv(gg.p[1], e1, N))) return rc;
+    gg.p[0].wscale = ws0; gg.p[1].wscale = ws1;
+    return gemm_dispatch(gg, 2, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" {
 
 int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
                   int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
                   const int64_t* out_rows, void* workspace, size_t workspace_bytes, void* stream) {
-    if (M == 0) return 0;
-    int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, epilogue, gate, resid);
-    if (rc) return rc;
-    GemmGroup gg;
-    fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, gate, resid, out_rows);
-    gg.p[1] = gg.p[0];
-    return gemm_dispatch(gg, 1, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm1(A, lda, W, ldw, nullptr, bias, C, ldc, M, N, K, epilogue, gelu_from_col, gate, resid, out_rows, workspace,
+                 workspace_bytes, stream);
 }
 
 int rgn_gemm_bf16_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
                        const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1,
                        const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1, int N,
                        int K, int epilogue, int gelu_from_col, void* workspace, size_t workspace_bytes, void* stream) {
-    if (M0 == 0 && M1 == 0) return 0;
-    if (M0 == 0) return rgn_gemm_bf16(A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, epilogue, gelu_from_col, gate1, resid1, nullptr, workspace, workspace_bytes, stream);
-    if (M1 == 0) return rgn_gemm_bf16(A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, epilogue, gelu_from_col, gate0, resid0, nullptr, workspace, workspace_bytes, stream);
-    int rc = check_problem(A0, lda0, W0, K, C0, ldc0, M0, N, K, epilogue, gate0, resid0);
-    if (rc) return rc;
-    rc = check_problem(A1, lda1, W1, K, C1, ldc1, M1, N, K, epilogue, gate1, resid1);
-    if (rc) return rc;
-    GemmGroup gg;
-    fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, gelu_from_col, gate0, resid0, nullptr);
-    fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, gelu_from_col, gate1, resid1, nullptr);
-    return gemm_dispatch(gg, 2, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm2(A0, lda0, W0, nullptr, bias0, C0, ldc0, M0, gate0, resid0, A1, lda1, W1, nullptr, bias1, C1, ldc1, M1, gate1,
+                 resid1, N, K, epilogue, gelu_from_col, workspace, workspace_bytes, stream);
 }
 
 int rgn_gemm_bf16_qkv(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
                       int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace, size_t workspace_bytes,
                       void* stream) {
-    if (M == 0) return 0;
-    int rc = check_problem(A, lda, W, ldw, C, ldc, M, N, K, RGN_EPI_QKV, nullptr, nullptr);
-    if (rc) return rc;
-    GemmGroup gg;
-    fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, nullptr, nullptr, nullptr);
-    if ((rc = fill_qkv(gg.p[0], e, N))) return rc;
-    gg.p[1] = gg.p[0];
-    return gemm_dispatch(gg, 1, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm_qkv1(A, lda, W, ldw, nullptr, bias, C, ldc, M, N, K, gelu_from_col, e, workspace, workspace_bytes, stream);
 }
 
 int rgn_gemm_bf16_qkv_pair(const void* A0, int lda0, const void* W0, const void* bias0, void* C0, int ldc0, int M0,
                            const rgn_qkv_epilogue* e0, const void* A1, int lda1, const void* W1, const void* bias1,
                            void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K, void* workspace,
                            size_t workspace_bytes, void* stream) {
-    if (M0 == 0 && M1 == 0) return 0;
-    if (M0 == 0) return rgn_gemm_bf16_qkv(A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, N, e1, workspace, workspace_bytes, stream);
-    if (M1 == 0) return rgn_gemm_bf16_qkv(A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, N, e0, workspace, workspace_bytes, stream);
-    int rc = check_problem(A0, lda0, W0, K, C0, ldc0, M0, N, K, RGN_EPI_QKV, nullptr, nullptr);
-    if (rc) return rc;
-    if ((rc = check_problem(A1, lda1, W1, K, C1, ldc1, M1, N, K, RGN_EPI_QKV, nullptr, nullptr))) return rc;
-    GemmGroup gg;
-    fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, N, nullptr, nullptr, nullptr);
-    fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, N, nullptr, nullptr, nullptr);
-    if ((rc = fill_qkv(gg.p[0], e0, N))) return rc;
-    if ((rc = fill_qkv(gg.p[1], e1, N))) return rc;
-    return gemm_dispatch(gg, 2, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
+    return gemm_qkv2(A0, lda0, W0, nullptr, bias0, C0, ldc0, M0, e0, A1, lda1, W1, nullptr, bias1, C1, ldc1, M1, e1, N, K,
+                     workspace, workspace_bytes, stream);
+}
+
+// ---- fp8 (OCP e4m3fn) weights with per-output-channel fp32 scales: same calls, W one byte per element -------------------
+int rgn_gemm_w8(const void* A, int lda, const void* W8, int ldw, const float* wscale, const void* bias, void* C, int ldc, int M,
+                int N, int K, int epilogue, int gelu_from_col, const void* gate, const void* resid, const int64_t* out_rows,
+                void* workspace, size_t workspace_bytes, void* stream) {
+    if (!wscale) return fail(RGN_E_BADARG, "gemm_w8: scale vector missing");
+    return gemm1(A, lda, W8, ldw, wscale, bias, C, ldc, M, N, K, epilogue, gelu_from_col, gate, resid, out_rows, workspace,
+                 workspace_bytes, stream);
+}
+
+int rgn_gemm_w8_pair(const void* A0, int lda0, const void* W0, const float* wscale0, const void* bias0, void* C0, int ldc0, int M0,
+                     const void* gate0, const void* resid0, const void* A1, int lda1, const void* W1, const float* wscale1,
+                     const void* bias1, void* C1, int ldc1, int M1, const void* gate1, const void* resid1, int N, int K,
+                     int epilogue, int gelu_from_col, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!wscale0 || !wscale1) return fail(RGN_E_BADARG, "gemm_w8: scale vector missing");
+    return gemm2(A0, lda0, W0, wscale0, bias0, C0, ldc0, M0, gate0, resid0, A1, lda1, W1, wscale1, bias1, C1, ldc1, M1, gate1,
+                 resid1, N, K, epilogue, gelu_from_col, workspace, workspace_bytes, stream);
+}
+
+int rgn_gemm_w8_qkv(const void* A, int lda, const void* W8, int ldw, const float* wscale, const void* bias, void* C, int ldc, int M,
+                    int N, int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    if (!wscale) return fail(RGN_E_BADARG, "gemm_w8: scale vector missing");
+    return gemm_qkv1(A, lda, W8, ldw, wscale, bias, C, ldc, M, N, K, gelu_from_col, e, workspace, workspace_bytes, stream);
+}
+
+int rgn_gemm_w8_qkv_pair(const void* A0, int lda0, const void* W0, const float* wscale0, const void* bias0, void* C0, int ldc0,
+                         int M0, const rgn_qkv_epilogue* e0, const void* A1, int lda1, const void* W1, const float* wscale1,
+                         const void* bias1, void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    if (!wscale0 || !wscale1) return fail(RGN_E_BADARG, "gemm_w8: scale vector missing");
+    return gemm_qkv2(A0, lda0, W0, wscale0, bias0, C0, ldc0, M0, e0, A1, lda1, W1, wscale1, bias1, C1, ldc1, M1, e1, N, K,
+                     workspace, workspace_bytes, stream);
 }
 
 size_t rgn_gemm_workspace_bytes(void) { return (size_t)256 << 20; }

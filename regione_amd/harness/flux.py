@@ -534,6 +534,29 @@ class FluxTransformer2DModel:
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         return self.load_state_dict_stream(sd.items())
 
+    # -- fp8 weights (BASELINE configs[4]) ----------------------------------------------------------------
+    def quantize_fp8_(self):
+        """Store the trunk's block GEMM weights (QKV(+MLP), out, FeedForward, proj_out of every block: > 99 % of the
+        parameters) as OCP e4m3fn with one fp32 scale per output channel (ops.quantize_w8).  Activations, biases, norms,
+        embedders and the AdaLN table stay bf16.  The GEMMs then read half the weight bytes; arithmetic is bf16 MFMA on the
+        exactly converted values, the scale multiplies the fp32 accumulator (rgn_gemm_w8*).  The last-block row skipping
+        (which slices weight rows) is switched off for a quantised trunk."""
+        def q(obj, name):
+            w = getattr(obj, name, None)
+            if w is not None and w.dtype == torch.bfloat16:
+                setattr(obj, name, ops.quantize_w8(w))
+        for blk in self.transformer_blocks:
+            for n in ("w_kvq", "w_add_kvq", "w_out", "w_add_out"):
+                q(blk.attn, n)
+            for n in ("ff_w1", "ff_w2", "ffc_w1", "ffc_w2"):
+                q(blk, n)
+        for blk in self.single_transformer_blocks:
+            q(blk.attn, "w_kvqm")
+            q(blk, "w_po")
+        self._fp8 = True
+        torch.cuda.empty_cache()
+        return self
+
     # -- embedders ------------------------------------------------------------------------------------
     def time_text_embed(self, timestep: torch.Tensor, guidance: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
         """[EXT] CombinedTimestepGuidanceTextProjEmbeddings; the three MLPs are M=1 GEMVs."""
@@ -616,7 +639,7 @@ class FluxTransformer2DModel:
         assert hidden_states.shape[0] == 1, "harness engine runs one image per forward"
         if out_rows is None:
             out_rows = self.__dict__.pop("out_rows_hint", None)
-        if not SKIP_UNREAD_ROWS:
+        if not SKIP_UNREAD_ROWS or getattr(self, "_fp8", False):
             out_rows = None
         M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
         Mo = M if out_rows is None else min(int(out_rows), M)
@@ -635,7 +658,7 @@ class FluxTransformer2DModel:
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
-        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo if SKIP_UNREAD_ROWS else None)
+        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo if (SKIP_UNREAD_ROWS and not getattr(self, "_fp8", False)) else None)
         for block in self.transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
         for block in self.single_transformer_blocks:

@@ -160,17 +160,45 @@ def gemm_workspace(device) -> torch.Tensor:
     return _gemm_ws[key]
 
 
+FP8 = torch.float8_e4m3fn
+
+
+def quantize_w8(W: torch.Tensor):
+    """bf16 weight [N, K] -> (fp8 e4m3fn [N, K], fp32 scale [N]): per-output-channel absmax / 448 (OCP e4m3fn max).  The
+    scale travels ON the quantised tensor (`._rgn_scale`), so call sites keep passing one weight object."""
+    w = W.float()
+    scale = (w.abs().amax(dim=1).clamp_min(1e-12) / 448.0)
+    q = (w / scale[:, None]).to(FP8).contiguous()
+    q._rgn_scale = scale.contiguous()
+    return q
+
+
+def _wscale(W: torch.Tensor) -> Optional[torch.Tensor]:
+    if W.dtype != FP8:
+        return None
+    s = getattr(W, "_rgn_scale", None)
+    if s is None:
+        raise _lib.RegionEHipError("fp8 weight without its per-channel scale (use ops.quantize_w8; slices lose the attribute)")
+    return s
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, epilogue: int = EPI_BIAS,
          gelu_from_col: int = 0, gate: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
          out_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[r] = epilogue(A @ W^T + bias).  A [M,K] (row stride may exceed K), W [N,K], out [*,N] view."""
-    assert A.dtype == W.dtype == out.dtype == torch.bfloat16
+    """out[r] = epilogue(A @ W^T + bias).  A [M,K] (row stride may exceed K), W [N,K] (bf16, or fp8 from quantize_w8), out [*,N] view."""
+    assert A.dtype == out.dtype == torch.bfloat16 and W.dtype in (torch.bfloat16, FP8)
     M, K = A.shape
     N = W.shape[0]
     assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and W.shape[1] == K and out.shape[1] == N
     if resid is not None:
         assert resid.stride(0) == out.stride(0) and resid.stride(1) == 1
     ws = gemm_workspace(A.device)
+    sc = _wscale(W)
+    if sc is not None:
+        rc = _lib.lib().rgn_gemm_w8(_p(A), A.stride(0), _p(W), W.stride(0), _p(sc), _p(bias), _p(out), out.stride(0), M, N, K,
+                                    epilogue, gelu_from_col, _p(gate), _p(resid), _p(out_rows), _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "rgn_gemm_w8")
+        return out
     rc = _lib.lib().rgn_gemm_bf16(_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                   epilogue, gelu_from_col, _p(gate), _p(resid), _p(out_rows), _p(ws), ws.numel() * 4,
                                   _stream())
@@ -187,6 +215,14 @@ def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, g
     for t in (A0, A1, out0, out1):
         assert t.stride(1) == 1 and t.dtype == torch.bfloat16
     ws = gemm_workspace(A0.device)
+    s0, s1 = _wscale(W0), _wscale(W1)
+    if s0 is not None or s1 is not None:
+        rc = _lib.lib().rgn_gemm_w8_pair(_p(A0), A0.stride(0), _p(W0), _p(s0), _p(b0), _p(out0), out0.stride(0), A0.shape[0],
+                                         _p(gate0), _p(resid0), _p(A1), A1.stride(0), _p(W1), _p(s1), _p(b1), _p(out1),
+                                         out1.stride(0), A1.shape[0], _p(gate1), _p(resid1), N, K, epilogue, gelu_from_col,
+                                         _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "rgn_gemm_w8_pair")
+        return
     rc = _lib.lib().rgn_gemm_bf16_pair(_p(A0), A0.stride(0), _p(W0), _p(b0), _p(out0), out0.stride(0), A0.shape[0],
                                        _p(gate0), _p(resid0), _p(A1), A1.stride(0), _p(W1), _p(b1), _p(out1),
                                        out1.stride(0), A1.shape[0], _p(gate1), _p(resid1), N, K, epilogue,
@@ -211,11 +247,17 @@ def gemm_qkv(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out
              gelu_from_col: Optional[int] = None) -> torch.Tensor:
     """QKV (+ fused MLP half) projection whose epilogue normalises / rotates Q and K, places K and V^T in the
     cache slabs and leaves Q (and GELU(mlp)) in `out`: rgn_gemm_bf16 + rgn_qk_norm_rope_store in one launch."""
-    assert A.dtype == W.dtype == out.dtype == torch.bfloat16
+    assert A.dtype == out.dtype == torch.bfloat16 and W.dtype in (torch.bfloat16, FP8)
     M, K = A.shape
     N = W.shape[0]
     assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and W.shape[1] == K and out.shape[1] == N
     ws = gemm_workspace(A.device)
+    sc = _wscale(W)
+    if sc is not None:
+        rc = _lib.lib().rgn_gemm_w8_qkv(_p(A), A.stride(0), _p(W), W.stride(0), _p(sc), _p(bias), _p(out), out.stride(0), M, N, K,
+                                        N if gelu_from_col is None else gelu_from_col, epi, _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "rgn_gemm_w8_qkv")
+        return out
     rc = _lib.lib().rgn_gemm_bf16_qkv(_p(A), A.stride(0), _p(W), W.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                       N if gelu_from_col is None else gelu_from_col, epi, _p(ws), ws.numel() * 4, _stream())
     _lib.check(rc, "rgn_gemm_bf16_qkv")
@@ -230,6 +272,13 @@ def gemm_qkv_pair(A0, W0, b0, out0, epi0, A1, W1, b1, out1, epi1):
     for t in (A0, A1, out0, out1):
         assert t.stride(1) == 1 and t.dtype == torch.bfloat16
     ws = gemm_workspace(A0.device)
+    s0, s1 = _wscale(W0), _wscale(W1)
+    if s0 is not None or s1 is not None:
+        rc = _lib.lib().rgn_gemm_w8_qkv_pair(_p(A0), A0.stride(0), _p(W0), _p(s0), _p(b0), _p(out0), out0.stride(0), A0.shape[0],
+                                             epi0, _p(A1), A1.stride(0), _p(W1), _p(s1), _p(b1), _p(out1), out1.stride(0),
+                                             A1.shape[0], epi1, N, K, _p(ws), ws.numel() * 4, _stream())
+        _lib.check(rc, "rgn_gemm_w8_qkv_pair")
+        return
     rc = _lib.lib().rgn_gemm_bf16_qkv_pair(_p(A0), A0.stride(0), _p(W0), _p(b0), _p(out0), out0.stride(0), A0.shape[0], epi0,
                                            _p(A1), A1.stride(0), _p(W1), _p(b1), _p(out1), out1.stride(0), A1.shape[0], epi1,
                                            N, K, _p(ws), ws.numel() * 4, _stream())

@@ -90,7 +90,7 @@ def test_foreign_layout_is_refused_before_anything_is_built():
     with pytest.raises(NotImplementedError):
         A.adopt_engine(other)
     with pytest.raises(NotImplementedError):
-        A.adopt(type("QwenImageEditPipeline", (), {})())
+        A.adopt(other)
 
 
 # ------------------------------------------------------------------------------------------------ GPU

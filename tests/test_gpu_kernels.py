@@ -436,3 +436,81 @@ def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, e
     ref = F.linear(A.float(), W.float(), b.float())
     if epi == "bias":
         assert rel_err(outs[1].cpu(), ref.cpu()) < 3e-3
+
+
+@pytest.mark.parametrize("M,N,K,epi,variant", [(8704, 3072, 3072, "bias", "2"), (1536, 21504, 3072, "gelu", "2"), (700, 3072, 15360, "gate", "2"),
+                                               (513, 520, 128, "bias", "1"), (300, 704, 256, "gate", "1"), (2000, 1000, 320, "bias", "2")])
+def test_gemm_fp8_weights_per_channel_scale(M, N, K, epi, variant, monkeypatch):
+    """rgn_gemm_w8: W stored as OCP e4m3fn + one fp32 scale per output channel.  Reference = the same GEMM on the
+    DEQUANTISED weights in fp32 (the conversion fp8 -> bf16 in the kernel is exact; the scale multiplies the fp32
+    accumulator): the result must agree to bf16 output rounding - tolerance 2^-8 relative + accumulation noise, like the
+    bf16 kernel against its fp32 reference."""
+    from regione_amd import ops
+    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = bf(torch.randn(M, K, generator=g)).cuda()
+    W = bf(torch.randn(N, K, generator=g) * 0.05 * (1 + torch.arange(N)[:, None] % 7)).cuda()     # rows of different magnitude
+    b = bf(torch.randn(N, generator=g)).cuda()
+    Wq = ops.quantize_w8(W)
+    assert Wq.dtype == torch.float8_e4m3fn and Wq._rgn_scale.shape == (N,)
+    Wd = Wq.float() * Wq._rgn_scale[:, None]                                    # what the kernel multiplies with
+    assert float((Wd - W.float()).abs().max() / W.float().abs().max()) < 0.07  # e4m3: 3 mantissa bits
+    gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
+    lin = A.float() @ Wd.T + b.float()
+    if epi == "gate":
+        o = x.clone()
+        ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
+        gated = (gate.float()[None] * bf(lin).float()).to(torch.bfloat16).float()
+        ref = x.float() + gated
+        mag = x.float().abs() + gated.abs() + gate.float().abs()[None] * 2 ** -8 * lin.abs()     # the terms, not their (cancelling) sum
+    elif epi == "gelu":
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GELU, gelu_from_col=N // 2 // 8 * 8)
+        ref = bf(lin).float()
+        c = N // 2 // 8 * 8
+        ref[:, c:] = F.gelu(ref[:, c:], approximate="tanh")
+    else:
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(A, Wq, b, o)
+        ref = lin
+    torch.cuda.synchronize()
+    err = (o.float() - ref).abs()
+    tol = 2 ** -7 * (mag if epi == "gate" else ref.abs()) + 2e-2
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert rel_err(o.cpu(), ref.cpu()) < 4e-3
+    # and close to the UNQUANTISED GEMM within the format's error (per-channel scaling keeps every row's relative error)
+    full = A.float() @ W.float().T + b.float()
+    if epi == "bias":
+        assert rel_err(o.cpu(), full.cpu()) < 4e-2
+
+
+def test_gemm_fp8_weights_fused_qkv_epilogue_and_pair():
+    """The fused Q/K/V epilogue and the two-problem launch on fp8 weights == the same calls on the dequantised bf16
+    weights up to the bf16 rounding of the dequantised matrix (K slab / V^T slab / Q compared)."""
+    from regione_amd import ops
+    M, H, K = 600, 2, 256
+    gen = torch.Generator().manual_seed(77)
+    A, W, b, wq, wk, rope, D, N, skv = _qkv_case(M, H, K, 1024, gen)
+    Wq = ops.quantize_w8(W)
+    Wd = bf(Wq.float() * Wq._rgn_scale[:, None])
+    outs = []
+    for w in (Wq, Wd):
+        ks = torch.zeros(skv, D, dtype=torch.bfloat16, device="cuda")
+        vs = torch.zeros(D, skv, dtype=torch.bfloat16, device="cuda")
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        epi = ops.qkv_epilogue(wq=wq, wk=wk, rope_q=rope, rope_k=rope, k_slab=ks, vt_slab=vs, H=H, k_col=0, v_col=D, q_col=2 * D)
+        ops.gemm_qkv(A, w, b, out, epi, gelu_from_col=3 * D)
+        outs.append((out[:, 2 * D:].clone(), ks, vs))
+    for a, r in zip(outs[0], outs[1]):
+        assert rel_err(a.cpu(), r.cpu()) < 6e-3
+    # pair: text + image problems in one launch == two single launches (bit-identical)
+    A1 = bf(torch.randn(90, K, generator=gen)).cuda()
+    W1q = ops.quantize_w8(bf(torch.randn(512, K, generator=gen) * 0.1).cuda())
+    W0q = ops.quantize_w8(bf(torch.randn(512, K, generator=gen) * 0.1).cuda())
+    b0 = bf(torch.randn(512, generator=gen)).cuda()
+    o0, o1 = torch.empty(M, 512, dtype=torch.bfloat16, device="cuda"), torch.empty(90, 512, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_pair(A, W0q, b0, o0, A1, W1q, b0, o1)
+    s0, s1 = torch.empty_like(o0), torch.empty_like(o1)
+    ops.gemm(A, W0q, b0, s0)
+    ops.gemm(A1, W1q, b0, s1)
+    assert torch.equal(o0, s0) and torch.equal(o1, s1)

@@ -346,3 +346,55 @@ def test_num_inference_steps_extension_with_caller_gamma(golden, cpu_ops):
     assert kinds == "".join(O.derive_schedule(L, "flux", 10, 4, "28", 0.04, n=50, gamma=table)).replace("S", "F")
     assert torch.equal(pipe._regione_manager.edited_ids, st.edited_ids)
     assert torch.equal(out, ref)
+
+
+def test_overlay_tool_matches_reference_arithmetic(tmp_path):
+    """tools/overlay.py: edited token id -> (id // W_tok, id % W_tok) cell, nearest x16 upsampling, white at alpha 160
+    composited like PIL.Image.alpha_composite (src/Step1X-Edit-v1p2/inplace.py:456-497)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import overlay as OV
+    from PIL import Image
+    h, w = 800, 1328                                     # the 50 x 83 token grid of demo_0.png (SURVEY.md App. A-9)
+    ids = torch.tensor([[0, 82, 83 * 49 + 82, 83 * 10 + 7]])
+    m = OV.token_ids_to_mask(ids.numpy(), h, w)
+    assert m.shape == (800, 1328) and int(m.sum()) == 4 * 256
+    assert m[:16, :16].all() and m[:16, 82 * 16:].all() and m[49 * 16:, 82 * 16:].all() and m[160:176, 112:128].all()
+    ref = torch.zeros(1, 1, 50, 83)
+    ref[:, :, ids[0] // 83, ids[0] % 83] = 1           # the reference's token_ids2hw_mask
+    ref = torch.nn.functional.interpolate(ref, scale_factor=16, mode="nearest")[0, 0].numpy().astype(np.uint8)
+    assert np.array_equal(m, ref)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    img[..., 3] = 255
+    layer = np.stack([m * 255] * 3 + [m * 160], -1).astype(np.uint8)
+    want = np.asarray(Image.alpha_composite(Image.fromarray(img, "RGBA"), Image.fromarray(layer, "RGBA")))
+    assert np.array_equal(OV.overlay_rgba(img, m), want)
+    out = tmp_path / "o.png"
+    OV.save_overlay(str(out), ids.numpy(), h, w)
+    assert np.array_equal(np.asarray(Image.open(out)) > 0, m.astype(bool))
+    with pytest.raises(ValueError):
+        OV.token_ids_to_mask([50 * 83], h, w)
+
+
+def test_scheduler_config_keys_honoured_or_refused():
+    """Advisor finding (round 1): a host scheduler config must not be silently truncated.  shift_terminal (Qwen-Image-Edit
+    ships 0.02), time_shift_type and invert_sigmas are implemented; karras / exponential / beta sigmas, stochastic sampling
+    and unknown keys are refused; the default schedule is still the oracle's, bit for bit."""
+    from regione_amd.harness import flux as H
+    sig = np.linspace(1.0, 1 / 28, 28)
+    mu = H.calculate_shift(4096)
+    s = H.FlowMatchEulerDiscreteScheduler()
+    s.set_timesteps(sigmas=sig, mu=mu)
+    osig, ots = O.flow_match_schedule(28, 4096)
+    assert torch.equal(s.sigmas, osig) and torch.equal(s.timesteps, ots)
+    q = H.FlowMatchEulerDiscreteScheduler.from_config(dict(shift_terminal=0.02, _class_name="FlowMatchEulerDiscreteScheduler"))
+    q.set_timesteps(sigmas=sig, mu=mu)
+    assert abs(float(q.sigmas[-2]) - 0.02) < 1e-6 and float(q.sigmas[0]) == 1.0 and float(q.sigmas[-1]) == 0.0
+    assert bool((q.sigmas[:-1] <= s.sigmas[:-1] + 1e-6).all())           # the tail is stretched DOWN to the terminal value
+    lin = H.FlowMatchEulerDiscreteScheduler(time_shift_type="linear")
+    lin.set_timesteps(sigmas=sig, mu=mu)
+    assert not torch.equal(lin.sigmas, s.sigmas)
+    for bad in (dict(use_karras_sigmas=True), dict(stochastic_sampling=True), dict(some_new_key=1), dict(time_shift_type="cubic")):
+        with pytest.raises(ValueError):
+            H.FlowMatchEulerDiscreteScheduler(**bad)

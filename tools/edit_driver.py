@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--toy", action="store_true", help="toy-size engine (plumbing check)")
     ap.add_argument("--compare", action="store_true", help="also run full-token and report latent PSNR per item")
+    ap.add_argument("--overlay_dir", type=str, default=None,
+                    help="with --use_regione: write <key>.mask.png per item - the edited-token partition painted on the pixel grid "
+                         "(tools/overlay.py; reference src/Step1X-Edit-v1p2/inplace.py:456-497)")
     a = ap.parse_args()
 
     from regione_amd.harness import flux as HF
@@ -75,6 +78,8 @@ def main():
         return pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=a.size, width=a.size, latents=lat,
                     num_inference_steps=a.num_inference_steps, guidance_scale=a.guidance_scale, return_dict=False)[0]
 
+    edited = []
+
     def run_all(tag):
         print("Warmup...", file=sys.stderr)
         for _ in range(3):
@@ -87,6 +92,13 @@ def main():
             torch.cuda.synchronize()
             t1 = time.time()
             times.append(t1 - t0)
+            M = getattr(pipe, "_regione_manager", None)
+            if a.overlay_dir and M is not None and M.edited_ids is not None:
+                from tools import overlay
+                os.makedirs(a.overlay_dir, exist_ok=True)
+                overlay.save_overlay(os.path.join(a.overlay_dir, os.path.basename(data["key"]) + ".mask.png"),
+                                     M.edited_ids.cpu().numpy(), a.size, a.size)
+                edited.append(int(M.edited_ids.shape[1]))
             print(f"[{tag} {index + 1} / {len(items)}] {data['key']}: {data['instruction']!r}  Time consuming: {t1 - t0}s", file=sys.stderr)
         return outs, times
 
@@ -95,7 +107,12 @@ def main():
     if a.use_regione:
         helper.enable()
     outs, times = run_all("RegionE" if a.use_regione else "full-token")
-    report = {"num_item": len(times), "ave_time_consuming": sum(times) / len(times), "time_consuming_list": times}
+    report = {"num_item": len(times), "ave_time_consuming": sum(times) / len(times), "time_consuming_list": times,
+              # end-to-end = encode + loop + decode (hosted pipelines report the three stages in `.timing`); this driver has no
+              # encoders / VAE (synthetic embeddings and latents), so its timed region is the loop alone
+              "stages": {"encode_s": 0.0, "loop_s": sum(times) / len(times), "decode_s": 0.0}}
+    if edited:
+        report["edited_tokens"] = edited
     if a.compare and a.use_regione:
         helper.disable()
         ref, rtimes = run_all("full-token")

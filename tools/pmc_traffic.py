@@ -47,6 +47,10 @@ def main():
         w = wr[k]["WRITE_SIZE"][1] * 1024 / wr[k]["WRITE_SIZE"][0]
         res[k] = dict(dispatches=n, read_bytes_raw_per_launch=raw, read_bytes_x2_per_launch=2 * raw, write_bytes_per_launch=w,
                       traffic_bytes_per_launch=2 * raw + w)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash
+    res["csrc_sha16"] = csrc_hash()          # bench.py quotes this file only for a build of the same kernel sources
     res["note"] = ("rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum (own pass) and --pmc WRITE_SIZE (own pass) over "
          "`bench.py --steps 1 --warmup 0`; read bytes = ((RDREQ-RDREQ_32B)*64 + RDREQ_32B*32), doubled per MI355X_MICROARCH.md "
          "(gfx950 tallies 128-B requests at 64 B); WRITE_SIZE in KiB.  L2->fabric requests: Infinity-Cache hits are included.")
