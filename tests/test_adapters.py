@@ -219,14 +219,15 @@ def test_hosted_flux_call_image_and_prompt_in_image_out():
     g = torch.Generator().manual_seed(5)
     picture = torch.rand(1, 3, 256, 256, generator=g)
     picture[:, :, 64:160, 96:192] = 0.0                      # something for the prompt to 'edit'
+    # _auto_resize=False: keep the toy 256 x 256 input (the default snaps to Kontext's training resolutions, ~1024^2 area)
     out = hosted(image=picture, prompt="make the square red", generator=torch.Generator().manual_seed(1), output_type="pt",
-                 guidance_scale=2.5)
+                 guidance_scale=2.5, _auto_resize=False)
     assert tuple(out.images.shape) == (1, 3, 256, 256) and torch.isfinite(out.images).all()
     assert [c[0] for c in calls] == ["encode_prompt", "prepare_latents", "unpack", "free"]
     assert calls[1][1:] == (256, 256, 16)
     # the loop the hosted call ran == the engine's own latent-level call on the same packed inputs
     lat = hosted(image=picture, prompt="make the square red", generator=torch.Generator().manual_seed(1), output_type="latent",
-                 guidance_scale=2.5).images
+                 guidance_scale=2.5, _auto_resize=False).images
     pe, pp, _ = host.encode_prompt(prompt="make the square red")
     l0, il, _, _ = host.prepare_latents(picture * 2 - 1, 1, 16, 256, 256, torch.bfloat16, None, torch.Generator().manual_seed(1))
     direct = hosted.engine(image=il.cuda(), prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(), height=256, width=256,
@@ -238,12 +239,12 @@ def test_hosted_flux_call_image_and_prompt_in_image_out():
     helper.enable()
     trace = {}
     reg = hosted(image=picture, prompt="make the square red", generator=torch.Generator().manual_seed(1), output_type="latent",
-                 guidance_scale=2.5, trace=trace).images
+                 guidance_scale=2.5, trace=trace, _auto_resize=False).images
     assert "".join(trace["kind"]).startswith("FFFFFF") and len(trace["kind"]) == 28
     assert torch.isfinite(reg.float()).all()
     helper.disable()
     again = hosted(image=picture, prompt="make the square red", generator=torch.Generator().manual_seed(1), output_type="latent",
-                   guidance_scale=2.5).images
+                   guidance_scale=2.5, _auto_resize=False).images
     assert torch.equal(again, lat)
     with pytest.raises(ValueError, match="batch-1"):
         hosted(image=picture, prompt=["a", "b"])

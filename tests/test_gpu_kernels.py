@@ -462,7 +462,9 @@ def test_gemm_fp8_weights_per_channel_scale(M, N, K, epi, variant, monkeypatch):
         ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
         gated = (gate.float()[None] * bf(lin).float()).to(torch.bfloat16).float()
         ref = x.float() + gated
-        mag = x.float().abs() + gated.abs() + gate.float().abs()[None] * 2 ** -8 * lin.abs()     # the terms, not their (cancelling) sum
+        # the terms, not their (cancelling) sum: a one-ulp flip of bf16(lin) (different fp32 accumulation order over K) moves
+        # the result by |gate| * ulp(lin)
+        mag = x.float().abs() + gated.abs() + gate.float().abs()[None] * lin.abs()
     elif epi == "gelu":
         o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GELU, gelu_from_col=N // 2 // 8 * 8)
