@@ -441,7 +441,7 @@ _HOSTED = {"FluxKontextPipeline": _hosted_flux, "Step1XEditPipeline": _hosted_st
 def is_engine_pipeline(pipe) -> bool:
     """True for a regione_amd.harness pipeline (latent-level, HIP transformer); False for a stock host pipeline."""
     from .harness import flux as HF
-    return isinstance(getattr(pipe, "transformer", None), HF.FluxTransformer2DModel)
+    return isinstance(pipe, HF.FluxKontextPipeline) or isinstance(getattr(pipe, "transformer", None), HF.FluxTransformer2DModel)
 
 
 class HostedPipeline:

@@ -22,6 +22,8 @@
 //     (4.4 MB at Skv = 8704) is fetched into that XCD's L2 once.
 #include "common.h"
 #include <stdlib.h>
+#include <utility>
+#include "attn_loop_asm.inc"
 
 namespace rgn {
 
@@ -306,6 +308,165 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 1 : 2) void attention_kernel(c
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Hand-scheduled variant (tools/gen_attn_loop.py -> attn_loop_asm.inc): same data layout, same LDS images, same results
+// up to fp32 summation order; the KV loop is ONE asm statement that overlaps, inside every wave, the MFMAs of one tile with
+// the softmax VALU of its neighbours.  8 waves x 32 query rows, five 32 KiB stages (all 160 KiB of LDS), Skv % 64 == 0.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_s;
+
+template <int B>
+__device__ __forceinline__ float agpr_read1() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(B));
+    return x;
+}
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <bool SPLIT, int AV = 0>
+__global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g) {
+    constexpr int NW = 8, QB = 256;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, half = lane >> 5;
+    const int nQ = (g.Sq + QB - 1) / QB;
+    int item, split = 0;
+    {
+        const int nb = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
+        const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
+        const int q = nb >> 3, r = nb & 7;
+        int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if (SPLIT) { split = u % g.nsplit; u /= g.nsplit; }
+        item = g.item_offset + u;
+    }
+    const int h = item / nQ, qb = item - h * nQ;
+    const int q0 = qb * QB + wave * 32;
+    const uint32_t HD2 = (uint32_t)g.H * 256u;                 // bytes of one K row (H * 128 bf16)
+
+    const int ntiles_all = g.Skv / KV_T;
+    int t_begin = 0, ntiles = ntiles_all;
+    if (SPLIT) {
+        const int per = (ntiles_all + g.nsplit - 1) / g.nsplit;
+        t_begin = split * per;
+        ntiles = max(0, min(per, ntiles_all - t_begin));
+    }
+    float m_run = -1e30f, l_run = 0.f;
+    if (ntiles > 0) {
+        // per-lane relative LDS addresses of the fragments (same swizzles as attention_kernel)
+        uint32_t krel[8], vrel[4];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) krel[ks] = ql * 256 + (((ks * 2 + half) ^ (ql & 15)) << 4);
+#pragma unroll
+        for (int kb4 = 0; kb4 < 4; ++kb4) vrel[kb4] = ql * 128 + (((kb4 * 2 + half) ^ ((ql >> 1) & 7)) << 4);
+        // per-lane source offsets of this wave's 2 + 2 DMA pieces (bytes from the slab bases)
+        uint32_t dk[2], dv[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int piece = wave * 2 + p;
+            const int krow = piece * 4 + (lane >> 4);
+            dk[p] = (uint32_t)krow * HD2 + h * 256 + (((lane & 15) ^ (krow & 15)) << 4);
+            const int vrow = piece * 8 + (lane >> 3);
+            dv[p] = (uint32_t)(h * 128 + vrow) * (uint32_t)(g.skv_pad * 2) + (((lane & 7) ^ ((vrow >> 1) & 7)) << 4);
+        }
+        const int qr = min(q0 + ql, g.Sq - 1);
+        const uint16_t* qptr = g.Q + (size_t)qr * g.ldq + h * 128 + half * 8;
+        auto rsrc = [](const void* p) {
+            const uint64_t a = (uint64_t)p;
+            u32x4_s r;
+            r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+            r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+            r[2] = 0xffffffffu;
+            r[3] = 0x00020000u;
+            return r;
+        };
+        const u32x4_s rk = rsrc(g.K), rv = rsrc(g.Vt);
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;    // 0: no static LDS
+        const uint32_t kadv = __builtin_amdgcn_readfirstlane((uint32_t)KV_T * HD2);
+        uint32_t tk = __builtin_amdgcn_readfirstlane((uint32_t)t_begin * kadv), tv = __builtin_amdgcn_readfirstlane((uint32_t)t_begin * 128u);
+        const uint32_t tk_last = __builtin_amdgcn_readfirstlane((uint32_t)(t_begin + ntiles - 1) * kadv);
+        const uint32_t tv_last = __builtin_amdgcn_readfirstlane((uint32_t)(t_begin + ntiles - 1) * 128u);
+        uint32_t stg_k = __builtin_amdgcn_readfirstlane(lds0 + 32768u), stg_v = __builtin_amdgcn_readfirstlane(lds0), stg_d = stg_v;
+        const uint32_t wdst = __builtin_amdgcn_readfirstlane((uint32_t)wave * 2048u);
+        uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) >> 1), rem = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) & 1u);
+        const float sl2e = g.scale_log2e;
+        uint32_t stmp, stmp2, sdst;
+#define RGN_ATTN_OPERANDS \
+                     : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k), \
+                       [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2), \
+                       [sdst] "=&s"(sdst) \
+                     : [krel0] "v"(krel[0]), [krel1] "v"(krel[1]), [krel2] "v"(krel[2]), [krel3] "v"(krel[3]), [krel4] "v"(krel[4]), \
+                       [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]), \
+                       [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), \
+                       [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last), \
+                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e) \
+                     : RGN_ATTN_LOOP_CLOBBERS
+        if constexpr (AV == 1) asm volatile(RGN_ATTN_LOOP_ASM_V1 RGN_ATTN_OPERANDS);
+        else if constexpr (AV == 2) asm volatile(RGN_ATTN_LOOP_ASM_V2 RGN_ATTN_OPERANDS);
+        else if constexpr (AV == 3) asm volatile(RGN_ATTN_LOOP_ASM_V3 RGN_ATTN_OPERANDS);
+        else if constexpr (AV == 4) asm volatile(RGN_ATTN_LOOP_ASM_V4 RGN_ATTN_OPERANDS);
+        else
+        asm volatile(RGN_ATTN_LOOP_ASM
+                     : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k),
+                       [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2),
+                       [sdst] "=&s"(sdst)
+                     : [krel0] "v"(krel[0]), [krel1] "v"(krel[1]), [krel2] "v"(krel[2]), [krel3] "v"(krel[3]), [krel4] "v"(krel[4]),
+                       [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]),
+                       [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]),
+                       [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last),
+                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e)
+                     : RGN_ATTN_LOOP_CLOBBERS);
+    }
+    // O^T accumulator: a[db * 16 + r] (zero when this split piece had no tiles - but then the launch has none either)
+    const float l_other = __shfl_xor(l_run, 32, 64);
+    const float l_tot = l_run + l_other;
+    if (SPLIT) {
+        float* base = g.ws + ((size_t)(item - g.item_offset) * g.nsplit + split) * (size_t)(QB * 130);
+        float* orow = base + (size_t)(wave * 32 + ql) * 128;
+        static_for<16>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;           // I = db * 4 + r4
+            constexpr int db = I / 4, r4 = I % 4;
+            *(float4*)(orow + db * 32 + 8 * r4 + 4 * half) =
+                make_float4(agpr_read1<db * 16 + r4 * 4 + 0>(), agpr_read1<db * 16 + r4 * 4 + 1>(),
+                            agpr_read1<db * 16 + r4 * 4 + 2>(), agpr_read1<db * 16 + r4 * 4 + 3>());
+        });
+        if (half == 0) {
+            base[QB * 128 + wave * 32 + ql] = m_run;
+            base[QB * 129 + wave * 32 + ql] = l_tot;
+        }
+        return;
+    }
+    const float inv = 1.0f / l_tot;
+    constexpr int OT_LD = 136;
+    uint16_t* ot = (uint16_t*)smem;                      // 256 rows x 136 bf16 = 68 KiB: fits, one pass
+    {
+        uint16_t* orow = ot + (wave * 32 + ql) * OT_LD;
+        static_for<16>([&](auto Ic) {
+            constexpr int I = decltype(Ic)::value;
+            constexpr int db = I / 4, r4 = I % 4;
+            const int d = db * 32 + 8 * r4 + 4 * half;
+            const uint32_t w0 = cvt_pk_bf16(agpr_read1<db * 16 + r4 * 4 + 0>() * inv, agpr_read1<db * 16 + r4 * 4 + 1>() * inv);
+            const uint32_t w1 = cvt_pk_bf16(agpr_read1<db * 16 + r4 * 4 + 2>() * inv, agpr_read1<db * 16 + r4 * 4 + 3>() * inv);
+            *(uint2*)(orow + d) = make_uint2(w0, w1);
+        });
+    }
+    __syncthreads();
+    constexpr int RPP = 512 / 16;
+#pragma unroll
+    for (int it = 0; it < QB / RPP; ++it) {
+        const int row = (tid >> 4) + it * RPP, c = (tid & 15) * 8;
+        const int qr2 = qb * QB + row;
+        if (qr2 < g.Sq) *(uint4*)(g.O + (size_t)qr2 * g.ldo + h * 128 + c) = *(const uint4*)(ot + row * OT_LD + c);
+    }
+}
+
 // Merge the nsplit partial results of each split item: O = sum_s O_s 2^(m_s - m*) / sum_s l_s 2^(m_s - m*).
 template <int QB>
 __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g) {
@@ -337,8 +498,41 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g
     *(uint4*)(g.O + (size_t)qr * g.ldo + h * 128 + c) = out;
 }
 
+template <bool SPLIT>
+static int launch_attention_asm(const AttnArgs& g, hipStream_t st) {
+    constexpr int LDS = 5 * ATT_STAGE;                   // 160 KiB
+    static bool attr[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr[dev]) {
+        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (dev >= 0 && dev < 64) attr[dev] = true;
+    }
+    const int nblocks = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
+    if (nblocks == 0) return 0;
+    // RGN_ATTN_ASMV (experiments): 1 / 2 = fragment prefetch distance 6 / 7; 3 / 4 = timing-only ablations (WRONG results)
+    static const int av = [] { const char* e = getenv("RGN_ATTN_ASMV"); return e ? atoi(e) : 0; }();
+#define RGN_LAUNCH_AV(N)                                                                                                   \
+    case N:                                                                                                                \
+        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT, N>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+        hipLaunchKernelGGL((attention_asm_kernel<SPLIT, N>), dim3(nblocks), dim3(512), LDS, st, g);                         \
+        break;
+    switch (av) {
+        RGN_LAUNCH_AV(1) RGN_LAUNCH_AV(2) RGN_LAUNCH_AV(3) RGN_LAUNCH_AV(4)
+        default: hipLaunchKernelGGL((attention_asm_kernel<SPLIT, 0>), dim3(nblocks), dim3(512), LDS, st, g);
+    }
+    return check_launch("attention_asm_kernel");
+}
+
+// RGN_ATTN_ASM=0: A/B switch back to the compiler-scheduled loop.  The asm loop needs whole KV tiles and 32-bit slab offsets.
+static bool attention_use_asm(const AttnArgs& g) {
+    static const int on = [] { const char* e = getenv("RGN_ATTN_ASM"); return e ? atoi(e) : 1; }();
+    return on && (g.Skv % KV_T) == 0 && (size_t)g.skv_pad * g.H * 256 < ((size_t)1 << 32);
+}
+
 template <int NW, int NSTAGE, bool SPLIT>
 static int launch_attention(const AttnArgs& g, hipStream_t st) {
+    if (NW == 8 && attention_use_asm(g)) return launch_attention_asm<SPLIT>(g, st);
     constexpr int LDS = NSTAGE * ATT_STAGE;
     static bool attr[64] = {};          // per device (one process may drive several GPUs)
     int dev = 0;

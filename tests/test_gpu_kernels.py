@@ -496,9 +496,10 @@ def test_gemm_fp8_weights_fused_qkv_epilogue_and_pair():
     Wq = ops.quantize_w8(W)
     Wd = bf(Wq.float() * Wq._rgn_scale[:, None])
     outs = []
+    pad = ops.padded(skv)
     for w in (Wq, Wd):
-        ks = torch.zeros(skv, D, dtype=torch.bfloat16, device="cuda")
-        vs = torch.zeros(D, skv, dtype=torch.bfloat16, device="cuda")
+        ks = torch.zeros(pad, D, dtype=torch.bfloat16, device="cuda")
+        vs = torch.zeros(D, pad, dtype=torch.bfloat16, device="cuda")
         out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
         epi = ops.qkv_epilogue(wq=wq, wk=wk, rope_q=rope, rope_k=rope, k_slab=ks, vt_slab=vs, H=H, k_col=0, v_col=D, q_col=2 * D)
         ops.gemm_qkv(A, w, b, out, epi, gelu_from_col=3 * D)

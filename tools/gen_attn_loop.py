@@ -1,0 +1,391 @@
+#!/usr/bin/env python3
+"""Generate the hand-scheduled KV loop of the 8-wave region attention kernel (regione_amd/csrc/attn_loop_asm.inc).
+
+    python tools/gen_attn_loop.py            # rewrites the .inc (committed; the build does not run this script)
+
+What the compiler-scheduled kernel (attention_kernel, attn.hip) does per KV tile and wave: 16 MFMAs (S^T = K Q^T), then
+~150 VALU instructions of softmax with the matrix pipe idle, then 16 MFMAs (O^T += V^T P^T).  Both waves of a SIMD pass the
+same barrier every tile, so their softmax phases coincide: a SIMD spends ~3780 cycles on 2048 cycles of MFMA work
+(DESIGN.md section 4.7).  hipcc cannot be made to software-pipeline this (round 1 tried).  Here the loop is ONE asm
+statement in which each wave overlaps its OWN phases:
+
+    X(t):  MFMA  S(t+1) = K(t+1) Q^T            ||  VALU  P(t) = exp2(S(t) * c - m),  P -> bf16 (pf)
+    Y(t):  MFMA  O += V^T(t) P(t)^T            ||  VALU  row sums of P(t),  max of S(t+1),  defer-max decision
+
+Two S register sets alternate (tile parity), so the loop body exists in two parities.  K / V^T fragments stream through an
+8-slot window (32 registers), each fragment requested 4 MFMAs before its use, with counted lgkmcnt waits.  K / V^T tiles
+arrive by LDS-DMA into a ring of FIVE 32 KiB stages (all 160 KiB): when a wave passes the tile barrier of body t every
+wave's pieces of tiles <= t+2 have landed, tile t+3 may be in flight and tile t+4 is issued right behind the barrier
+(two tiles of lead; the fragment prefetch may run across the barrier).  Past the last tile the DMA re-fetches the last tile
+(clamped offset), which keeps every `vmcnt` count uniform.  Online softmax with deferred max exactly like the C++ kernel
+(running max raised - and O, l rescaled - only when some row's tile max exceeds it by > 2^8); the rescale sits at the head of
+X(t+1), after PV(t) has drained.
+
+Registers (per wave; 2 waves per SIMD -> 256 in total):
+    a[0:63]    O^T accumulator (4 d-blocks x 16)          a[64:95]  Q fragments (B operand of S^T), 8 k-steps x 4
+    v[32:63]   S set 0 (s0 = kv rows 0..31, s1 = 32..63)   v[64:95]  S set 1
+    v[96:111]  pf: P packed to bf16 (B operand of PV)      v[112:143] fragment window, 8 slots x 4
+    v[144:159] temporaries                                 v[0:31]   operands (compiler-allocated)
+Named operands: see attn.hip (attention_asm_kernel).
+"""
+import os
+
+S_BASE = (32, 64)
+PF, FR, TMP = 96, 112, 144
+T_NEGM, T_MX, T_MXB, T_KA, T_VA, T_A, T_B, T_ALPHA = (TMP + i for i in range(8))
+ACC = [TMP + 8 + i for i in range(4)]           # row-sum accumulators
+T_R = [TMP + 12 + i for i in range(4)]          # rescale temporaries
+K_TILE, STAGE, NSTAGE = 16384, 32768, 5
+LDS_END = STAGE * NSTAGE
+CFG = dict(D=4, novalu=False, noread=False, prio=False)      # generator knobs (main() emits several variants)
+
+
+def v(n, w=1):
+    return f"v{n}" if w == 1 else f"v[{n}:{n + w - 1}]"
+
+
+def a(n, w=1):
+    return f"a{n}" if w == 1 else f"a[{n}:{n + w - 1}]"
+
+
+def slot(i):
+    return v(FR + 4 * (i % 8), 4)
+
+
+class Stream:
+    """Instruction list with LDS-read bookkeeping for counted lgkmcnt waits."""
+
+    def __init__(self):
+        self.ins = []
+        self.pending = []            # fragment tags of ds_reads issued and not yet known complete (in issue order)
+
+    def emit(self, s):
+        self.ins.append(s)
+
+    def read(self, tag, dst, addr, off):
+        if CFG["noread"]:
+            return
+        self.ins.append(f"ds_read_b128 {dst}, {addr} offset:{off}")
+        self.pending.append(tag)
+
+    def need(self, tag):
+        """make sure the read `tag` has completed: LDS reads return in order"""
+        if tag in self.pending:
+            i = self.pending.index(tag)
+            n = len(self.pending) - 1 - i
+            self.ins.append(f"s_waitcnt lgkmcnt({n})")
+            self.pending = self.pending[i + 1:]
+
+
+def k_addr(st, ks):
+    st.emit(f"v_add_u32 {v(T_KA)}, %[stg_k], %[krel{ks}]")
+
+
+def v_addr(st, kb4):
+    st.emit(f"v_add_u32 {v(T_VA)}, %[stg_v], %[vrel{kb4}]")
+
+
+def k_read(st, f):                 # K fragment f = 2*ks + b  (b = kv half of the tile)
+    ks, b = divmod(f, 2)
+    if b == 0:
+        k_addr(st, ks)
+    st.read(("K", f), slot(f), v(T_KA), b * 8192)
+
+
+def v_read(st, g):                 # V^T fragment g = 4*kb4 + db
+    kb4, db = divmod(g, 4)
+    if db == 0:
+        v_addr(st, kb4)
+    st.read(("V", g), slot(g), v(T_VA), K_TILE + db * 4096)
+
+
+def qk_mfma(st, f, q):
+    ks, b = divmod(f, 2)
+    d = v(S_BASE[q] + 16 * b, 16)
+    c = "0" if ks == 0 else d
+    st.need(("K", f))
+    st.emit(f"v_mfma_f32_32x32x16_bf16 {d}, {slot(f)}, {a(64 + 4 * ks, 4)}, {c}")
+
+
+def pv_mfma(st, g):
+    kb4, db = divmod(g, 4)
+    st.need(("V", g))
+    st.emit(f"v_mfma_f32_32x32x16_bf16 {a(16 * db, 16)}, {slot(g)}, {v(PF + 4 * kb4, 4)}, {a(16 * db, 16)}")
+
+
+def exp_ops(p):
+    """VALU of X(t) on S set p, in place: P = exp2(S * c - m); pf[k] = bf16x2(P[2k], P[2k+1]).  Ordered so that an op never
+    follows its producer closely."""
+    b = S_BASE[p]
+    fma = lambda i: f"v_fma_f32 {v(b + i)}, {v(b + i)}, %[sl2e], {v(T_NEGM)}"
+    exp = lambda i: f"v_exp_f32 {v(b + i)}, {v(b + i)}"
+    cvt = lambda k: f"v_cvt_pk_bf16_f32 {v(PF + k)}, {v(b + 2 * k)}, {v(b + 2 * k + 1)}"
+    ops = [fma(i) for i in range(8)]
+    for i in range(32 + 12):
+        if i < 32:
+            ops.append(exp(i))
+        if i + 8 < 32:
+            ops.append(fma(i + 8))
+        j = i - 10
+        if 0 <= j < 32 and j % 2 == 1:
+            ops.append(cvt(j // 2))
+    assert sum(o.startswith("v_cvt") for o in ops) == 16
+    return ops
+
+
+def rowsum_ops(p):
+    b = S_BASE[p]
+    ops = [f"v_mov_b32 {v(ACC[i])}, {v(b + i)}" for i in range(4)]
+    ops += [f"v_add_f32 {v(ACC[i % 4])}, {v(ACC[i % 4])}, {v(b + i)}" for i in range(4, 32)]
+    ops += [f"v_add_f32 {v(ACC[0])}, {v(ACC[0])}, {v(ACC[1])}", f"v_add_f32 {v(ACC[2])}, {v(ACC[2])}, {v(ACC[3])}",
+            f"v_add_f32 {v(ACC[0])}, {v(ACC[0])}, {v(ACC[2])}", f"v_add_f32 %[l_run], %[l_run], {v(ACC[0])}"]
+    return ops
+
+
+def max_ops(q):
+    """tile max of S set q (two chains), across the two half-waves, scaled; vcc = rows whose max exceeds m_run + 8"""
+    b = S_BASE[q]
+    ops = [f"v_max_f32 {v(T_MX)}, {v(b)}, {v(b + 1)}", f"v_max_f32 {v(T_MXB)}, {v(b + 16)}, {v(b + 17)}"]
+    for i in range(1, 8):
+        ops.append(f"v_max3_f32 {v(T_MX)}, {v(T_MX)}, {v(b + 2 * i)}, {v(b + 2 * i + 1)}")
+        ops.append(f"v_max3_f32 {v(T_MXB)}, {v(T_MXB)}, {v(b + 16 + 2 * i)}, {v(b + 17 + 2 * i)}")
+    ops += [f"v_max_f32 {v(T_MX)}, {v(T_MX)}, {v(T_MXB)}",
+            f"v_mov_b32 {v(T_A)}, {v(T_MX)}", f"v_mov_b32 {v(T_B)}, {v(T_MX)}", "s_nop 1",
+            f"v_permlane32_swap_b32 {v(T_A)}, {v(T_B)}",               # lanes 32-63 of A <-> lanes 0-31 of B
+            f"v_max_f32 {v(T_MX)}, {v(T_A)}, {v(T_B)}",
+            f"v_mul_f32 {v(T_MX)}, %[sl2e], {v(T_MX)}",
+            f"v_add_f32 {v(T_A)}, 0x41000000, %[m_run]",                  # m_run + 8.0 (DEFER_THR)
+            f"v_cmp_gt_f32 vcc, {v(T_MX)}, {v(T_A)}"]
+    return ops
+
+
+def rescale_block(st, tag):
+    """head of X: if any row's new tile max exceeds the running max by more than 2^8 (vcc from the previous Y), raise the
+    running max and rescale l and O.  PV of the previous tile has issued; its results need ~20 wait states."""
+    st.emit(f"s_cbranch_vccz 9{tag}f")
+    st.emit("s_nop 15")
+    st.emit("s_nop 15")
+    st.emit(f"v_max_f32 {v(T_A)}, %[m_run], {v(T_MX)}")                 # m_new
+    st.emit(f"v_sub_f32 {v(T_ALPHA)}, %[m_run], {v(T_A)}")
+    st.emit(f"v_exp_f32 {v(T_ALPHA)}, {v(T_ALPHA)}")                    # alpha = 2^(m_old - m_new)
+    st.emit(f"v_mov_b32 %[m_run], {v(T_A)}")
+    st.emit(f"v_sub_f32 {v(T_NEGM)}, 0, {v(T_A)}")
+    st.emit(f"v_mul_f32 %[l_run], %[l_run], {v(T_ALPHA)}")
+    for i in range(0, 64, 4):
+        for k in range(4):
+            st.emit(f"v_accvgpr_read_b32 {v(T_R[k])}, {a(i + k)}")
+        for k in range(4):
+            st.emit(f"v_mul_f32 {v(T_R[k])}, {v(T_R[k])}, {v(T_ALPHA)}")
+        for k in range(4):
+            st.emit(f"v_accvgpr_write_b32 {a(i + k)}, {v(T_R[k])}")
+    st.emit(f"9{tag}:")
+
+
+def advance(st, reg):
+    st.emit(f"s_add_u32 %[{reg}], %[{reg}], {STAGE}")
+    st.emit(f"s_cmp_ge_u32 %[{reg}], {LDS_END}")
+    st.emit(f"s_cselect_b32 %[stmp], {LDS_END}, 0")
+    st.emit(f"s_sub_u32 %[{reg}], %[{reg}], %[stmp]")
+
+
+def dma_issue(st):
+    """4 pieces of the next tile (clamped to the last one) into stage stg_d; advance the tile offsets and stg_d"""
+    st.emit("s_min_u32 %[stmp], %[tk], %[tk_last]")
+    st.emit("s_min_u32 %[stmp2], %[tv], %[tv_last]")
+    st.emit("s_add_u32 %[sdst], %[stg_d], %[wdst]")
+    for p in range(2):
+        st.emit(f"s_add_u32 m0, %[sdst], {p * 1024}")
+        st.emit("s_nop 0")
+        st.emit(f"buffer_load_dwordx4 %[dk{p}], %[rk], %[stmp] offen lds")
+    for p in range(2):
+        st.emit(f"s_add_u32 m0, %[sdst], {K_TILE + p * 1024}")
+        st.emit("s_nop 0")
+        st.emit(f"buffer_load_dwordx4 %[dv{p}], %[rv], %[stmp2] offen lds")
+    st.emit("s_add_u32 %[tk], %[tk], %[kadv]")
+    st.emit("s_add_u32 %[tv], %[tv], 128")
+    advance(st, "stg_d")
+
+
+def interleave(st, mfmas, fillers, per_gap):
+    """emit the MFMA callbacks with `per_gap[i]` fillers behind MFMA i (fillers: strings or callables(st))"""
+    fi = 0
+    for i, m in enumerate(mfmas):
+        m(st)
+        for _ in range(per_gap[i] if i < len(per_gap) else 0):
+            if fi < len(fillers):
+                f = fillers[fi]
+                fi += 1
+                f(st) if callable(f) else st.emit(f)
+    while fi < len(fillers):
+        f = fillers[fi]
+        fi += 1
+        f(st) if callable(f) else st.emit(f)
+
+
+def spread(n_fill, n_gaps, first=0):
+    """distribute n_fill fillers over n_gaps gaps as evenly as possible, none before gap `first`"""
+    gaps = [0] * n_gaps
+    live = n_gaps - first
+    for k in range(n_fill):
+        gaps[first + (k * live) // max(n_fill, 1)] += 1
+    return gaps
+
+
+def phase_x(st, p, full):
+    """X(t), S(t) in set p: exp of tile t; with `full` also the QK MFMAs of tile t+1 into set 1-p.
+    Entry: K fragments 0..D-1 of tile t+1 requested (slots 0..D-1).  Exit: V fragments 0..D-1 of tile t requested.
+    Fragment i of a phase lives in slot i % 8; it is requested D MFMAs before its use: behind MFMA i-D-1... i.e. read(i + D)
+    follows MFMA i - 1 / precedes MFMA i; the first D fragments of the NEXT phase are requested behind this phase's
+    MFMA j + 8 (the last user of slot j)."""
+    D = CFG["D"]
+    q = 1 - p
+    vops = [] if CFG["novalu"] else exp_ops(p)
+    if not full:
+        for o in vops:
+            st.emit(o)
+        for g in range(D):
+            v_read(st, g)
+        return
+    mf = []
+    for f in range(16):
+        def m(st, f=f):
+            if f + D < 16:
+                k_read(st, f + D)
+            qk_mfma(st, f, q)
+            if f >= 8 and f - 8 < D:                       # slot f-8 is free now: V prefetch for Y(t)
+                v_read(st, f - 8)
+        mf.append(m)
+    gaps = spread(len(vops), 16)
+    interleave(st, mf, vops, gaps)
+
+
+def phase_y(st, p, full, prefetch_k):
+    """Y(t): PV MFMAs of tile t (P in set p / pf); row sums of P(t); with `full` the max + defer decision of S(t+1) (set 1-p);
+    with `prefetch_k` the first D K fragments of tile t+2 for the next X.  Entry: V fragments 0..D-1 requested."""
+    D = CFG["D"]
+    q = 1 - p
+    vops = [] if CFG["novalu"] else rowsum_ops(p)
+    mops = max_ops(q) if full else []
+    if CFG["novalu"] and mops:
+        mops = mops[-1:]                                    # keep vcc defined
+    mf = []
+    for g in range(16):
+        def m(st, g=g):
+            if g + D < 16:
+                v_read(st, g + D)
+            pv_mfma(st, g)
+            if prefetch_k and g >= 8 and g - 8 < D:         # slot g-8 is free now: K prefetch for X(t+1)
+                k_read(st, g - 8)
+        mf.append(m)
+    # the max reads S(t+1), written by the last QK MFMA of X(t): keep it behind the 4th PV MFMA
+    fill = vops[:8] + mops + vops[8:] if mops else vops
+    gaps = spread(len(fill), 16, first=3 if mops else 0)
+    interleave(st, mf, fill, gaps)
+
+
+def body(st, p, full, tag):
+    rescale_block(st, tag)
+    if full:
+        st.emit("s_waitcnt vmcnt(4)")                      # tile t+2 has landed (t+3 may be in flight)
+        st.emit("s_barrier")
+        dma_issue(st)                                      # tile t+4 -> the stage of tile t-1
+    phase_x(st, p, full)
+    if full:
+        advance(st, "stg_k")                               # next X reads K of tile t+2
+    phase_y(st, p, full, prefetch_k=full)
+    advance(st, "stg_v")
+    # a trailing full body's K prefetch reads (t+2) are harmless when tile t+2 does not exist: the clamped DMA re-fetched
+    # the last tile into that stage
+
+
+def prologue(st):
+    # Q fragments -> fragment window (plain loads), then the first four tiles
+    for ks in range(8):
+        st.emit(f"global_load_dwordx4 {slot(ks)}, %[qptr], off offset:{ks * 32}")
+    for _ in range(4):
+        dma_issue(st)
+    for n in range(64):
+        st.emit(f"v_accvgpr_write_b32 {a(n)}, 0")
+    st.emit("s_waitcnt vmcnt(16)")                         # Q landed (the 16 DMA pieces may be in flight)
+    for ks in range(8):
+        for k in range(4):
+            st.emit(f"v_accvgpr_write_b32 {a(64 + 4 * ks + k)}, {v(FR + 4 * ks + k)}")
+    st.emit(f"v_sub_f32 {v(T_NEGM)}, 0, %[m_run]")
+    st.emit("s_waitcnt vmcnt(8)")                          # tiles 0, 1 landed
+    st.emit("s_barrier")
+    # S(0) = K(0) Q^T into set 0 (stage 0: stg_v), not overlapped
+    st.emit("s_mov_b32 %[stmp], %[stg_k]")
+    st.emit("s_mov_b32 %[stg_k], %[stg_v]")
+    D = CFG["D"]
+    for f in range(D):
+        k_read(st, f)
+    for f in range(16):
+        if f + D < 16:
+            k_read(st, f + D)
+        qk_mfma(st, f, 0)
+    st.emit("s_mov_b32 %[stg_k], %[stmp]")
+    st.emit("s_nop 15")
+    st.emit("s_nop 15")
+    for o in max_ops(0):
+        st.emit(o)
+    for f in range(D):                                      # K prefetch of tile 1 for X(0)
+        k_read(st, f)
+
+
+def emit():
+    st = Stream()
+    prologue(st)
+    entry = [] if CFG["noread"] else [("K", f) for f in range(CFG["D"])]      # LDS reads in flight at every body entry
+    assert st.pending == entry
+    st.emit("s_cmp_eq_u32 %[cnt], 0")
+    st.emit("s_cbranch_scc1 2f")
+    st.emit("1:")
+    body(st, 0, True, "1")
+    body(st, 1, True, "2")
+    assert set(st.pending) <= set(entry)                 # the loop head assumed at least these reads in flight: conservative
+    st.emit("s_sub_u32 %[cnt], %[cnt], 1")
+    st.emit("s_cmp_lg_u32 %[cnt], 0")
+    st.emit("s_cbranch_scc1 1b")
+    st.emit("2:")
+    st.emit("s_cmp_eq_u32 %[rem], 0")
+    st.emit("s_cbranch_scc1 3f")
+    body(st, 0, True, "3")
+    body(st, 1, False, "4")
+    st.emit("s_branch 4f")
+    st.emit("3:")
+    st.pending = list(entry)
+    body(st, 0, False, "5")
+    st.emit("4:")
+    st.emit("s_waitcnt vmcnt(0)")
+    st.emit("s_waitcnt lgkmcnt(0)")
+    st.emit("s_barrier")
+    st.emit("s_nop 15")
+    st.emit("s_nop 15")
+    return st.ins
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = os.path.join(here, "..", "regione_amd", "csrc", "attn_loop_asm.inc")
+    variants = [("RGN_ATTN_LOOP_ASM", dict(D=4)), ("RGN_ATTN_LOOP_ASM_V1", dict(D=6)), ("RGN_ATTN_LOOP_ASM_V2", dict(D=7)),
+                ("RGN_ATTN_LOOP_ASM_V3", dict(D=4, novalu=True)), ("RGN_ATTN_LOOP_ASM_V4", dict(D=4, noread=True))]
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen_attn_loop.py - do not edit.  Hand-scheduled KV loop of attention_asm_kernel.\n")
+        f.write("// V1 / V2: fragment prefetch distance 6 / 7; V3 / V4: timing-only ablations (no softmax VALU / no LDS reads).\n")
+        for name, kw in variants:
+            CFG.update(dict(D=4, novalu=False, noread=False, prio=False))
+            CFG.update(kw)
+            lines = emit()
+            n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+            f.write(f"// {name}: {len(lines)} instructions, {n_mfma} MFMAs\n")
+            f.write(f"#define {name} \\\n")
+            for l in lines:
+                f.write(f'    "{l}\\n\\t" \\\n')
+            f.write('    ""\n')
+        clob = [f'"a{n}"' for n in range(96)] + [f'"v{n}"' for n in range(32, 160)] + ['"memory"', '"scc"', '"vcc"']
+        f.write("#define RGN_ATTN_LOOP_CLOBBERS " + ", ".join(clob) + "\n")
+    print(f"wrote {os.path.normpath(out)}")
+
+
+if __name__ == "__main__":
+    main()
