@@ -45,23 +45,23 @@ class RegionEHelper(object):
     def __init__(self, pipeline=None):
         # Three kinds of `pipeline`:
         #   * a regione_amd.harness pipeline (latent-level, HIP transformer): patched directly;
-        #   * a STOCK diffusers pipeline object (the reference's case, RegionE/README.md:85-113): its transformer weights are
-        #     adopted onto the HIP engine once (regione_amd.adapters.attach, kept at pipeline._regione_engine), the patch set
-        #     goes on that engine, and enable() swaps pipeline.__class__ so the user keeps calling pipeline(image=, prompt=);
+        #   * a STOCK diffusers pipeline object (the reference's case, RegionE/README.md:85-113): enable() adopts its transformer
+        #     weights onto the HIP engine once (regione_amd.adapters.attach, kept at pipeline._regione_engine), puts the patch
+        #     set on that engine and swaps pipeline.__class__, so the user keeps calling pipeline(image=, prompt=);
+        #     like the reference's, this constructor only looks at the class name;
         #   * a regione_amd.adapters.HostedPipeline wrapper (host + engine): the patch set goes on its engine.
         self.host = None
         if pipeline is not None:
             from .. import adapters
             if not adapters.is_engine_pipeline(pipeline) and not isinstance(pipeline, adapters.HostedPipeline):
-                if adapters._host_name(pipeline) not in config:
-                    raise KeyError(f"RegionE has no patch set for pipeline class {pipeline.__class__.__name__}")
                 self.host = pipeline
-                self.pipeline = adapters.attach(pipeline)
+                self.pipeline = pipeline
+                self.name = adapters._host_name(pipeline)
             else:
                 self.pipeline = getattr(pipeline, "_regione_engine", pipeline)
-        self.name = self.pipeline.__class__.__name__
-        if self.name.startswith("RegionE") and getattr(self.pipeline, "_regione_vanilla_class", None) is not None:
-            self.name = self.pipeline._regione_vanilla_class.__name__        # a second helper on an enabled pipeline
+                self.name = self.pipeline.__class__.__name__
+                if self.name.startswith("RegionE") and getattr(self.pipeline, "_regione_vanilla_class", None) is not None:
+                    self.name = self.pipeline._regione_vanilla_class.__name__        # a second helper on an enabled pipeline
         # per-helper copy: the reference mutates the module-level dict in set_params (RegionE.py:43-51),
         # which leaks settings between helpers; same defaults, no leak.
         self.config = copy.deepcopy(config[self.name])
@@ -72,19 +72,30 @@ class RegionEHelper(object):
         except ModuleNotFoundError as e:
             raise NotImplementedError(f"RegionE patch set for {self.name} is not built yet") from e
 
+    def _engine(self):
+        """The HIP pipeline the patch set goes on: `self.pipeline`, or - stock host pipeline - its adopted engine."""
+        if self.host is None:
+            return self.pipeline
+        from .. import adapters
+        return adapters.attach(self.host)
+
     def enable(self):
         assert self.pipeline is not None
-        self.pipeline = self._family().warp_modules(self.pipeline, **self.config)
+        eng = self._family().warp_modules(self._engine(), **self.config)
         if self.host is not None:
             from .. import adapters
             adapters.swap_host_class(self.host)          # hook (1) on the user's own pipeline object
+        else:
+            self.pipeline = eng
 
     def disable(self):
         assert self.pipeline is not None
-        self.pipeline = self._family().unwarp_modules(self.pipeline)
+        eng = self._family().unwarp_modules(self._engine())
         if self.host is not None:
             from .. import adapters
             adapters.restore_host_class(self.host)
+        else:
+            self.pipeline = eng
 
     def shard_cfg_branches(self, pair):
         """Extension: run the 'cond' and 'uncond' forwards of one image on the two ranks of
@@ -94,7 +105,7 @@ class RegionEHelper(object):
         if pair is not None and _FAMILY[self.name] not in ("QwenImageEdit", "QwenImageEditPlus", "Step1XEditV1P2"):
             raise NotImplementedError(f"{self.name} does not run CFG as two independent forwards (FLUX is guidance-distilled, "
                                       "Step1X-Edit v1p1 batches the branches): shard by image instead")
-        self.pipeline._cfg_pair = pair
+        self._engine()._cfg_pair = pair
 
     def set_params(self, num_inference_steps=28, warmup_step=None, post_step=None, refresh_step=None, threshold=None,
                    cache_threshold=None, erosion_dilation=None, strict_reference=None, gamma=None):

@@ -34,10 +34,12 @@ def _gen():
 def test_flux_stock_pipeline_call_shape():
     pipe = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
     cls = type(pipe)
-    helper = RegionEHelper(pipe)                                 # weights adopted here (pipe._regione_engine)
-    assert helper.name == "FluxKontextPipeline" and A.is_engine_pipeline(helper.pipeline) and not A.is_engine_pipeline(pipe)
+    helper = RegionEHelper(pipe)                                 # like the reference's: only the class name is read here
+    assert helper.name == "FluxKontextPipeline" and helper.pipeline is pipe and not A.is_engine_pipeline(pipe)
+    assert getattr(pipe, "_regione_engine", None) is None
     helper.set_params(threshold=0.5)
-    helper.enable()
+    helper.enable()                                              # weights adopted here, once (pipe._regione_engine)
+    assert A.is_engine_pipeline(pipe._regione_engine) and helper._engine() is pipe._regione_engine
     assert type(pipe).__name__ == "RegionEFluxKontextPipeline" and isinstance(pipe, cls)
     trace = {}
     out = pipe(image=_picture(), prompt="make the square red", generator=_gen(), output_type="pt", guidance_scale=2.5,
@@ -53,13 +55,13 @@ def test_flux_stock_pipeline_call_shape():
                preferred_resolutions=[(256, 256)]).images
     pe, pp, _ = pipe.encode_prompt(prompt="make the square red")
     l0, il, _, _ = pipe.prepare_latents(_picture() * 2 - 1, 1, 16, 256, 256, torch.bfloat16, None, _gen())
-    direct = helper.pipeline(image=il.cuda(), prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(), height=256, width=256,
-                             latents=l0.cuda(), guidance_scale=2.5, return_dict=False)[0]
+    direct = helper._engine()(image=il.cuda(), prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(), height=256, width=256,
+                               latents=l0.cuda(), guidance_scale=2.5, return_dict=False)[0]
     assert torch.equal(lat, direct)
     helper.disable()
     assert type(pipe) is cls and getattr(pipe, "_regione_host_class", None) is None
     # a second helper re-uses the adopted engine instead of copying 12 B parameters again
-    assert RegionEHelper(pipe).pipeline is helper.pipeline
+    assert RegionEHelper(pipe)._engine() is helper._engine()
     with pytest.raises(KeyError):
         RegionEHelper(type("StableDiffusionPipeline", (), {"transformer": None})())
 
@@ -89,7 +91,7 @@ def test_step1x_stock_pipeline_call_shape_with_host_connector(v1p2):
     # the connector ran once per branch per COMPUTED forward, never on cache-served steps
     computed = kinds.count("F") + kinds.count("R")
     assert conn.calls == 2 * computed and kinds.count("C") > 0
-    assert "connector" not in helper.pipeline.transformer.__dict__          # hook removed after the call
+    assert "connector" not in helper._engine().transformer.__dict__          # hook removed after the call
     # deterministic; image-space output goes through the host's decode + _output_process_image
     conn.calls = 0
     kw["generator"] = _gen()
@@ -146,7 +148,7 @@ def test_qwen_plus_list_of_condition_images():
     L = 64 * 64                                                    # last image 1:1 -> 1024 x 1024 -> 64 x 64 tokens
     assert out.shape == (1, L, 64) and torch.isfinite(out.float()).all() and len(trace["kind"]) == 28
     assert pipe.calls[0] == ("encode_prompt", "put the object of image 1 into image 2", 2)
-    eng = helper.pipeline
+    eng = helper._engine()
     M = eng._regione_manager
     # first image 2:1 -> calculate_dimensions(1024^2, 2) = 1440 x 736 -> 46 x 90 tokens; K/V rows = T + L + both images
     n1 = (736 // 16) * (1440 // 16)
