@@ -25,6 +25,7 @@ from typing import Optional
 import torch
 
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..harness import flux as H
 from .utils import FluxKontextManager, ids_gather
 
@@ -132,7 +133,7 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
             should_cache, ratio = avd_decide(MANAGER, avd, i, timesteps)
             if should_cache:                                                    # inplace.py:315-318
                 first_hit = cache.shape[1] != latents.shape[1]
-                noise_pred = ops.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
+                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
                 if first_hit:
                     cache = ids_gather(cache, MANAGER.edited_ids)
             else:
@@ -154,7 +155,7 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                                            encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,
                                            img_ids=latent_ids, joint_attention_kwargs={"tag": "uncond"},
                                            return_dict=False)[0][:, : latents.size(1)]
-                    noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
+                    noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
                 cache = noise_pred                                              # inplace.py:365
             if trace is not None:
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))
@@ -218,19 +219,19 @@ class RegionEFlowMatchEulerDiscreteScheduler(H.FlowMatchEulerDiscreteScheduler):
             MANAGER.prev_refresh_step = MANAGER.refresh_step_real_time.pop(0) - 1
             dt_final = float(s[-1] - sigma)
             dt_direct = float(s[MANAGER.prev_refresh_step] - sigma)
-            e, u, mask, _, _ = ops.arp_partition(
+            e, u, mask = TO.R.arp_partition(
                 sample, model_output, MANAGER.condition_latent, dt_final, MANAGER.threshold,
                 MANAGER.height // (MANAGER.patch_size * MANAGER.vae_scale_factor),
                 MANAGER.width // (MANAGER.patch_size * MANAGER.vae_scale_factor), MANAGER.erosion_dilation)
             MANAGER.set_partition(e, u, mask)
-            prev = ops.euler_step(sample, model_output, dt, MANAGER.edited_mask, dt_direct)
+            prev = TO.R.split_euler_step(sample, model_output, dt, MANAGER.edited_mask, dt_direct)
         elif MANAGER.prev_refresh_step is not None and cur == MANAGER.prev_refresh_step:   # :636-639, :665-677
             if len(MANAGER.refresh_step_real_time) != 0:
                 MANAGER.next_refresh_step = MANAGER.refresh_step_real_time.pop(0) - 1
             dt_direct = float(s[MANAGER.next_refresh_step] - sigma)
-            prev = ops.euler_step(sample, model_output, dt, MANAGER.edited_mask, dt_direct)
+            prev = TO.R.split_euler_step(sample, model_output, dt, MANAGER.edited_mask, dt_direct)
         else:
-            prev = ops.euler_step(sample, model_output, dt)                       # :680
+            prev = TO.R.split_euler_step(sample, model_output, dt)                       # :680
         self._step_index += 1
         return (prev,) if not return_dict else H._Cfg(prev_sample=prev)
 

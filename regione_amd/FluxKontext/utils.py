@@ -16,16 +16,18 @@ from typing import List, Optional
 import torch
 
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 
 
 def ids_gather(latent: torch.Tensor, ids: torch.Tensor, rope: bool = False, condition_length=None) -> torch.Tensor:
     """out[b,k,:] = latent[b, ids[b,k], :]  (reference utils.py:260-279)."""
-    return ops.gather_rows(latent, ids)
+    return TO.R.gather_rows(latent, ids)
 
 
 def ids_scatter(gathered_latent: torch.Tensor, ids: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """src[b, ids[b,k], :] = gathered_latent[b,k,:] in place; returns src (reference utils.py:240-257)."""
-    return ops.scatter_rows_(gathered_latent, ids, src)
+    TO.R.scatter_rows_(gathered_latent, ids, src)
+    return src
 
 
 def remove_scattered_points(binary_matrix: torch.Tensor, kernel_size: int = 3, kernel_type: str = "square") -> torch.Tensor:
@@ -44,7 +46,7 @@ def token_selector(tensor1, tensor2, k, similarity_type="cosine", height=-1, wid
     h_tok, w_tok = height // (patch_size * vae_scale_factor), width // (patch_size * vae_scale_factor)
     if not erosion_dilation and (h_tok * w_tok != tensor1.shape[1]):
         h_tok, w_tok = 1, tensor1.shape[1]
-    e, u, _, _, _ = ops.arp_partition(tensor1, None, tensor2, 0.0, k, h_tok, w_tok, erosion_dilation)
+    e, u, _ = TO.R.arp_partition(tensor1, None, tensor2, 0.0, k, h_tok, w_tok, erosion_dilation)
     return e, u
 
 
@@ -125,7 +127,7 @@ class FluxKontextManager:
 
     def rope_q_for(self, T: int, full_table):
         if T not in self._ropeq_by_T:
-            self._ropeq_by_T[T] = tuple(ops.gather_rows(t, self.sel_rows_for(T)) for t in full_table)
+            self._ropeq_by_T[T] = tuple(TO.R.gather_rows(t, self.sel_rows_for(T)) for t in full_table)
         return self._ropeq_by_T[T]
 
     def _compact(self, latent, latent_ids):

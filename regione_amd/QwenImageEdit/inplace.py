@@ -15,6 +15,7 @@ import torch
 
 from .. import dist as D
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..FluxKontext import inplace as fk
 from ..harness import flux as H
 from ..harness import qwen as HQ
@@ -97,7 +98,7 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
             should_cache, ratio = fk.avd_decide(MANAGER, avd, i, timesteps, self.gamma)      # :332-350
             if should_cache:                                                             # :352-356
                 first_hit = cache.shape[1] != latents.shape[1]
-                noise_pred = ops.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
+                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
                 if first_hit:
                     cache = ids_gather(cache, MANAGER.edited_ids)
             else:
@@ -113,7 +114,7 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
                     noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                                          lambda: branch(prompt_embeds, "cond"),
                                                          lambda: branch(negative_prompt_embeds, "uncond"))
-                    noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
+                    noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
                 else:
                     noise_pred = branch(prompt_embeds, "cond")
                 cache = noise_pred

@@ -19,6 +19,7 @@ import torch
 
 from .. import dist as D
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..FluxKontext import inplace as fk
 from ..harness import flux as H
 from ..harness import step1x as HS
@@ -90,7 +91,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
             should_cache, ratio = fk.avd_decide(MANAGER, avd, i, timesteps, gamma)
             if should_cache:
                 first_hit = cache.shape[1] != latents.shape[1]
-                noise_pred = ops.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
+                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
                 if first_hit:
                     cache = ids_gather(cache, MANAGER.edited_ids)
             else:
@@ -107,7 +108,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
                                               lambda: branch(prompt_embeds, text_ids, "cond"),
                                               lambda: branch(negative_prompt_embeds, neg_text_ids, "uncond"))
                 mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN                    # :421
-                noise_pred = ops.cfg_combine(pos, neg, true_cfg_scale, mode, process_norm_power)
+                noise_pred = TO.R.cfg_combine(pos, neg, true_cfg_scale, mode, process_norm_power)
                 cache = noise_pred
             if trace is not None:
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))

@@ -38,6 +38,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..synth import FluxConfig
 
 
@@ -148,7 +149,7 @@ class FlowMatchEulerDiscreteScheduler:
             self._init_step_index(timestep)
         i = self._step_index
         dt = float(self.sigmas[i + 1] - self.sigmas[i])
-        prev = ops.euler_step(sample, model_output, dt)
+        prev = TO.R.split_euler_step(sample, model_output, dt)
         self._step_index += 1
         return (prev,) if not return_dict else _Cfg(prev_sample=prev)
 
@@ -293,9 +294,7 @@ class FluxAttnProcessor:
         # bf16 (fused_kernels.py:80, quirk A-3): every row of a single-stream block, the image rows of a double-stream one
         partial = kv_rows is not None
         ctx.partial_kv = partial
-        if fuse:
-            epi = dict(rope_q=image_rotary_emb, rope_k=rope_k, k_slab=k_slab, vt_slab=vt_slab, H=H, k_col=0, v_col=d,
-                       q_col=2 * d, kv_rows=kv_rows)
+        (cos_q, sin_q), (cos_k, sin_k) = image_rotary_emb, rope_k
         n_out = ctx.out_rows if (block is not None and getattr(block, "is_last", False)) else None
         if not self.single:
             if n_out is not None and not partial:
@@ -309,22 +308,22 @@ class FluxAttnProcessor:
                 ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
                                        k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
                 q = wide[lo:hi, 2 * d:3 * d]
-                ops.attention(q, k_slab, vt_slab, q, skv, H)
+                TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
                 g_img, _ = block.gates_msa(ctx)
                 ops.gemm(q, attn.w_out, attn.b_out, ws.x[lo:hi], epilogue=ops.EPI_GATE_RESID, gate=g_img, resid=ws.x[lo:hi])
                 return ws.x[T:R], ws.x[:T]
             if fuse:       # projections + RMSNorm + RoPE + K / V^T cache placement of both streams: ONE launch
-                ops.gemm_qkv_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
-                                  ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, row_base=T, fp16_roundtrip=partial, **epi),
-                                  ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d],
-                                  ops.qkv_epilogue(wq=attn.norm_added_q, wk=attn.norm_added_k, row_base=0, **epi))
+                TO.R.kv_partial_update_pair_(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d], attn.norm_q, attn.norm_k,
+                                             ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d], attn.norm_added_q,
+                                             attn.norm_added_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_slab, vt_slab, H, T,
+                                             1e-6, partial)
             else:
                 ops.gemm_pair(ws.nrm[T:R], attn.w_kvq, attn.b_kvq, wide[T:R, :3 * d],
                               ws.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wide[:T, :3 * d])
                 ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
                                        k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
             q = wide[:, 2 * d:3 * d]
-            ops.attention(q, k_slab, vt_slab, q, skv, H)
+            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
             g_img, g_txt = block.gates_msa(ctx)
             ops.gemm_pair(q[T:R], attn.w_out, attn.b_out, ws.x[T:R], q[:T], attn.w_add_out, attn.b_add_out, ws.x[:T],
                           epilogue=ops.EPI_GATE_RESID, gate0=g_img, resid0=ws.x[T:R], gate1=g_txt, resid1=ws.x[:T])
@@ -341,18 +340,17 @@ class FluxAttnProcessor:
             ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
                                    vt_slab, kv_rows)
             q = wide[lo:hi, 2 * d:3 * d]
-            ops.attention(q, k_slab, vt_slab, q, skv, H)
+            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
             return wide[lo:hi, 2 * d:]
         if fuse:
-            ops.gemm_qkv(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide,
-                         ops.qkv_epilogue(wq=attn.norm_q, wk=attn.norm_k, fp16_roundtrip=partial, **epi),
-                         gelu_from_col=3 * d)
+            TO.R.kv_partial_update_(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, attn.norm_q, attn.norm_k, cos_q, sin_q, cos_k,
+                                    sin_k, kv_rows, k_slab, vt_slab, H, 0, 1e-6, partial, 3 * d)
         else:
             ops.gemm(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, epilogue=ops.EPI_GELU, gelu_from_col=3 * d)
             ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
                                    vt_slab, kv_rows)
         q = wide[:, 2 * d:3 * d]
-        ops.attention(q, k_slab, vt_slab, q, skv, H)
+        TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
         return wide[:, 2 * d:]                                       # cat([attn_output, mlp_hidden], dim=2)
 
 
@@ -757,7 +755,7 @@ class FluxKontextPipeline:
                                        pooled_projections=negative_pooled_prompt_embeds,
                                        encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,
                                        img_ids=latent_ids, return_dict=False)[0][:, : latents.size(1)]
-                noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
+                noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             if callback_on_step_end is not None:
                 callback_on_step_end(self, i, t, {"latents": latents})

@@ -18,6 +18,7 @@ import torch
 
 from .. import dist as D
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..synth import FluxConfig
 from . import flux as H
 
@@ -148,7 +149,7 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
                 noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                                      lambda: branch(prompt_embeds, "cond"),
                                                      lambda: branch(negative_prompt_embeds, "uncond"))
-                noise_pred = ops.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
+                noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
             else:
                 noise_pred = branch(prompt_embeds, "cond")
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]

@@ -17,6 +17,7 @@ import torch
 
 from .. import dist as D
 from .. import ops
+from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..synth import FluxConfig
 from . import flux as H
 
@@ -80,7 +81,7 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
     def _cfg(self, noise_pred, t, true_cfg_scale, timesteps_truncate, process_norm_power):
         pos, neg = noise_pred[0:1], noise_pred[1:2]
         mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN      # inplace.py:401
-        return ops.cfg_combine(pos.contiguous(), neg.contiguous(), true_cfg_scale, mode, process_norm_power)
+        return TO.R.cfg_combine(pos.contiguous(), neg.contiguous(), true_cfg_scale, mode, process_norm_power)
 
     def _batched_inputs(self, x, prompt_embeds, negative_prompt_embeds):
         return torch.cat((x, x), dim=0), torch.cat((prompt_embeds, negative_prompt_embeds), dim=0)
@@ -140,7 +141,7 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
                                       lambda: branch(prompt_embeds, pooled_prompt_embeds, text_ids, "cond"),
                                       lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond"))
             mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN
-            noise_pred = ops.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
+            noise_pred = TO.R.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
         if not return_dict:
             return (latents,)

@@ -7,6 +7,11 @@ schemas with their mutation annotations (`Tensor(a!)`), and have fake (meta) imp
 The native boundary stays the C ABI of include/regione_hip.h; nothing here computes - every op forwards to
 the HIP library and raises if it is missing (no CPU fallback).
 
+This IS the surface the engine runs on: the family patch sets (`regione_amd/<Family>/inplace.py`, `utils.py`) and the
+attention processors (`harness/*.py`) call these ops through the dispatcher (`R = torch.ops.regione_mi`); only the
+[EXT] block bodies around them (LayerNorm-modulate, FeedForward / out-projection GEMMs) call `regione_amd.ops` directly.
+`RGN_TORCH_OPS=0` sends the same calls straight to `regione_amd.ops` (A/B for the dispatcher's host cost).
+
     import regione_amd.torch_ops            # registers the ops (idempotent)
     e, u, mask = torch.ops.regione_mi.arp_partition(sample, v, cond, dt_final, 0.88, 64, 64, True)
 
@@ -19,6 +24,7 @@ the HIP library and raises if it is missing (no CPU fallback).
 | avd_apply            | `cache = ids_gather(cache, ids); noise_pred = cache * ratio`, inplace.py:315-318 |
 | cfg_combine          | inplace.py:364; Step1XEdit/inplace.py:401-410; QwenImageEdit/inplace.py:401-405 |
 | kv_partial_update_   | `_partially_linear` x2 + norm_k + RoPE into the K / V^T caches, inplace.py:734-794, fused_kernels.py:81-101 |
+| kv_partial_update_pair_ | the same for the two streams of a double-stream block (one launch), inplace.py:734-794 |
 | region_attention     | flash_attn_func / SDPA of the edited-token queries against the full cache, inplace.py:796-806 |
 """
 from __future__ import annotations
@@ -87,17 +93,39 @@ _define("cfg_combine", "(Tensor pos, Tensor neg, float scale, int mode=0, float 
 
 
 # ---- Region-Instruction KV cache ------------------------------------------------------------------
-def _kv_update(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base=0, eps=1e-6):
+def _epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip):
     d = heads * 128
-    epi = ops.qkv_epilogue(wq=norm_q, wk=norm_k, rope_q=(cos_q, sin_q), rope_k=(cos_k, sin_k), k_slab=k_cache,
-                           vt_slab=vt_cache, H=heads, k_col=0, v_col=d, q_col=2 * d, kv_rows=kv_rows, row_base=row_base, eps=eps)
-    ops.gemm_qkv(x, w_kvq, b_kvq, q_out, epi, gelu_from_col=3 * d)
+    return ops.qkv_epilogue(wq=norm_q, wk=norm_k, rope_q=(cos_q, sin_q), rope_k=(cos_k, sin_k), k_slab=k_cache,
+                            vt_slab=vt_cache, H=heads, k_col=0, v_col=d, q_col=2 * d, kv_rows=kv_rows, row_base=row_base,
+                            eps=eps, fp16_roundtrip=fp16_roundtrip)
+
+
+def _kv_update(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base=0,
+               eps=1e-6, fp16_roundtrip=False, gelu_from_col=-1):
+    epi = _epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip)
+    ops.gemm_qkv(x, w_kvq, b_kvq, q_out, epi, gelu_from_col=3 * heads * 128 if gelu_from_col < 0 else gelu_from_col)
 
 
 _define("kv_partial_update_",
         "(Tensor x, Tensor w_kvq, Tensor? b_kvq, Tensor(a!) q_out, Tensor norm_q, Tensor norm_k, Tensor cos_q, Tensor sin_q, "
         "Tensor cos_k, Tensor sin_k, Tensor? kv_rows, Tensor(b!) k_cache, Tensor(c!) vt_cache, int heads, int row_base=0, "
-        "float eps=1e-6) -> ()", _kv_update, lambda *a, **k: None)
+        "float eps=1e-6, bool fp16_roundtrip=False, int gelu_from_col=-1) -> ()", _kv_update, lambda *a, **k: None)
+
+
+def _kv_update_pair(x_img, w_img, b_img, out_img, norm_q_img, norm_k_img, x_txt, w_txt, b_txt, out_txt, norm_q_txt, norm_k_txt,
+                    cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps=1e-6, fp16_roundtrip=False):
+    e_img = _epi(norm_q_img, norm_k_img, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps, fp16_roundtrip)
+    e_txt = _epi(norm_q_txt, norm_k_txt, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, 0, eps, False)
+    ops.gemm_qkv_pair(x_img, w_img, b_img, out_img, e_img, x_txt, w_txt, b_txt, out_txt, e_txt)
+
+
+# both streams of a double-stream block in one launch: image rows sit behind the `txt_len` text rows of the shared
+# [text ; image] sequence (cache rows, rotary rows); only the image rows are ever partial (fp16 round trip, quirk A-3)
+_define("kv_partial_update_pair_",
+        "(Tensor x_img, Tensor w_img, Tensor? b_img, Tensor(a!) out_img, Tensor norm_q_img, Tensor norm_k_img, "
+        "Tensor x_txt, Tensor w_txt, Tensor? b_txt, Tensor(b!) out_txt, Tensor norm_q_txt, Tensor norm_k_txt, "
+        "Tensor cos_q, Tensor sin_q, Tensor cos_k, Tensor sin_k, Tensor? kv_rows, Tensor(c!) k_cache, Tensor(d!) vt_cache, "
+        "int heads, int txt_len, float eps=1e-6, bool fp16_roundtrip=False) -> ()", _kv_update_pair, lambda *a, **k: None)
 
 
 def _region_attention(q, k_cache, vt_cache, out, skv, heads, scale=-1.0):
@@ -111,3 +139,20 @@ _define("region_attention",
 
 def registered() -> Tuple[str, ...]:
     return tuple(sorted(_defined))
+
+
+class _Direct:
+    """`RGN_TORCH_OPS=0`: the same names bound straight to regione_amd.ops (no dispatcher) - A/B switch only."""
+    arp_partition = staticmethod(_arp)
+    gather_rows = staticmethod(ops.gather_rows)
+    scatter_rows_ = staticmethod(_scatter)
+    split_euler_step = staticmethod(lambda sample, v, dt, mask=None, dt_direct=0.0: ops.euler_step(sample, v, dt, mask, dt_direct))
+    avd_apply = staticmethod(ops.avd_apply)
+    cfg_combine = staticmethod(ops.cfg_combine)
+    kv_partial_update_ = staticmethod(_kv_update)
+    kv_partial_update_pair_ = staticmethod(_kv_update_pair)
+    region_attention = staticmethod(_region_attention)
+
+
+import os as _os
+R = _Direct if _os.environ.get("RGN_TORCH_OPS", "1") == "0" else getattr(torch.ops, NS)

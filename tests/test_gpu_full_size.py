@@ -25,8 +25,10 @@ def test_flux_1024_full_size_properties(golden):
     box = make_box(h, w, 0.25)
     B.install_region_injection(pipe, h, w, box, img[0:1], seed=7)
     trace = {}
+    stepped = []                                                   # scheduler outputs BEFORE the manager compacts / restores them
     out = pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=1024, width=1024, latents=lat,
-               guidance_scale=2.5, return_dict=False, trace=trace)[0]
+               guidance_scale=2.5, return_dict=False, trace=trace,
+               callback_on_step_end=lambda p, i, t, kw: stepped.append(kw["latents"].clone()))[0]
     M = pipe._regione_manager
     kinds = "".join(trace["kind"])
     # (1) the F/R/C plan is the one the REFERENCE's loop executes at this sequence length (tests/golden/loop_plan_64.npz)
@@ -57,6 +59,20 @@ def test_flux_1024_full_size_properties(golden):
     # (5) everything finite, and the region steps only ever touched the edited rows: between the partition and the
     #     refresh the unedited rows of the reassembled latent do not move
     assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
+    ei, ui = M.edited_ids.squeeze(0), M.unedited_ids.squeeze(0)
+    held, compactions, restores = None, 0, 0
+    for before, after in zip(stepped, trace["latents"]):
+        if before.shape[1] == L and after.shape[1] == K:                        # partition / re-compaction after a refresh
+            held = before[0, ui]
+            assert torch.equal(after[0], before[0, ei])
+            compactions += 1
+        elif before.shape[1] == K and after.shape[1] == L:                      # restore before a refresh / the tail
+            assert torch.equal(after[0, ui], held), "unedited rows moved while the loop ran on the edited rows only"
+            assert torch.equal(after[0, ei], before[0])
+            restores += 1
+        else:
+            assert torch.equal(after, before)
+    assert compactions == restores == 2 and len(stepped) == 28                  # partition + one forced refresh (step 16)
 
 
 def test_qwen_1024_full_size_plan_and_partition(golden):

@@ -98,7 +98,7 @@ def test_toy_forward_matches_oracle_full_step(golden):
     out = pipe.transformer(hidden_states=x.cuda(), timestep=tstep, guidance=guidance, pooled_projections=pooled.cuda(),
                            encoder_hidden_states=prompt.cuda(), txt_ids=torch.zeros(T, 3), img_ids=ids,
                            return_dict=False)[0].cpu()
-    assert torch.equal(ref, g["np0"].new_tensor(ref))            # sanity: ref is a finite tensor
+    assert torch.isfinite(ref.float()).all() and ref.shape == out.shape
     err = (out.float() - ref.float()).norm() / ref.float().norm()
     assert float(err) < 2e-2, float(err)
     assert O.psnr(out, ref) > 40.0

@@ -38,12 +38,13 @@ def cpu_ops(monkeypatch):
         fam = {0: "flux", 1: "step1x", 2: "qwen"}[mode]
         return O.cfg_combine(fam, pos, neg, scale, t=torch.tensor(1e9), power=power)
 
-    monkeypatch.setattr(ops, "cfg_combine", cfg)
-    monkeypatch.setattr(ops, "arp_partition", arp)
-    monkeypatch.setattr(ops, "euler_step", euler)
-    monkeypatch.setattr(ops, "avd_apply", avd)
-    monkeypatch.setattr(ops, "gather_rows", lambda x, ids: O.ids_gather(x, ids) if x.dim() == 3 else x[ids.reshape(-1)])
-    monkeypatch.setattr(ops, "scatter_rows_", lambda s, ids, d: O.ids_scatter(s, ids, d))
+    # the product reaches its kernels through torch.ops.regione_mi (regione_amd.torch_ops.R): stand in for that namespace
+    import types
+    from regione_amd import torch_ops
+    monkeypatch.setattr(torch_ops, "R", types.SimpleNamespace(
+        cfg_combine=cfg, arp_partition=lambda *a: arp(*a)[:3], split_euler_step=euler, avd_apply=avd,
+        gather_rows=lambda x, ids: O.ids_gather(x, ids) if x.dim() == 3 else x[ids.reshape(-1)],
+        scatter_rows_=lambda s, ids, d: O.ids_scatter(s, ids, d)))
     monkeypatch.setattr(fk, "ids_gather", lambda x, ids, *a, **k: O.ids_gather(x, ids))
 
 

@@ -8,7 +8,7 @@ import regione_amd.torch_ops as T
 
 def test_ops_are_registered_with_schemas():
     assert set(T.registered()) == {"arp_partition", "gather_rows", "scatter_rows_", "split_euler_step", "avd_apply",
-                                   "cfg_combine", "kv_partial_update_", "region_attention"}
+                                   "cfg_combine", "kv_partial_update_", "kv_partial_update_pair_", "region_attention"}
     s = str(torch.ops.regione_mi.scatter_rows_.default._schema)
     assert "Tensor(a!) dst" in s
     s = str(torch.ops.regione_mi.kv_partial_update_.default._schema)
@@ -82,3 +82,50 @@ def test_torch_ops_equal_ctypes_wrappers():
     torch.ops.regione_mi.region_attention(q[0][:, 2 * d:], kc[0], vc[0], o0, skv, H)
     ops.attention(q[1][:, 2 * d:], kc[1], vc[1], o1, skv, H)
     assert torch.equal(o0, o1) and torch.isfinite(o0.float()).all()
+
+
+@pytest.mark.gpu
+def test_engine_runs_on_the_registered_op_surface():
+    """One toy 28-step RegionE edit under a dispatch recorder: the ops SURVEY.md 8(b) names are the ones the product's
+    patch set and attention processors actually dispatch (not a side registration next to a ctypes path)."""
+    from collections import Counter
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from regione_amd import RegionEHelper, synth
+    from regione_amd.harness import flux as H
+
+    class Recorder(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.seen = Counter()
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            if name.startswith("regione_mi."):
+                self.seen[name.split(".")[1]] += 1
+            return func(*args, **(kwargs or {}))
+
+    cfg = synth.FluxConfig(**synth.TOY)
+    h = w = 16
+    T = 32
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=0.05)
+    lat, img, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=3, dtype=torch.bfloat16)
+    pipe = H.FluxKontextPipeline(H.FluxTransformer2DModel(cfg, "cuda:0").load_state_dict(wts))
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.1)
+    helper.enable()
+    trace = {}
+    kw = dict(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(), height=h * 16, width=w * 16,
+              latents=lat.cuda(), guidance_scale=2.5, return_dict=False)
+    with Recorder() as rec:
+        out = pipe(trace=trace, **kw)[0]
+    kinds = trace["kind"]
+    computed = kinds.count("F") + kinds.count("R")
+    n_blocks = cfg.n_double + cfg.n_single
+    assert rec.seen["arp_partition"] == 1 and rec.seen["split_euler_step"] == 28
+    assert rec.seen["region_attention"] == computed * n_blocks
+    assert rec.seen["kv_partial_update_pair_"] == computed * cfg.n_double
+    # the last single block of a FULL step projects K/V and Q/MLP in two plain launches (rows nothing reads, DESIGN 4.5b)
+    assert rec.seen["kv_partial_update_"] == kinds.count("R") * cfg.n_single + kinds.count("F") * (cfg.n_single - 1)
+    assert rec.seen["avd_apply"] == kinds.count("C") and rec.seen["gather_rows"] >= 2 and rec.seen["scatter_rows_"] >= 2
+    # same edit without the recorder: bit-identical (the dispatcher adds no arithmetic)
+    assert torch.equal(out, pipe(**kw)[0])
