@@ -330,34 +330,58 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <bool SPLIT, int AV = 0>
+// SPLIT: 0 = one workgroup per item (256 query rows of one head against every KV tile), result written in place;
+//        1 = every item cut into g.nsplit equal KV ranges (partials to g.ws, attention_combine_kernel merges);
+//        2 = stream-K: the (item, KV tile) steps of the launch, flattened item-major, are dealt out in equal contiguous
+//            runs to the gridDim.x workgroups; a run crosses at most one item boundary, so a workgroup works through one
+//            or two SEGMENTS (partials to slot 2 * unit + seg, attention_combine_sk_kernel merges).
+template <int SPLIT>
 __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g) {
     constexpr int NW = 8, QB = 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 31, half = lane >> 5;
     const int nQ = (g.Sq + QB - 1) / QB;
-    int item, split = 0;
+    const int ntiles_all = g.Skv / KV_T;
+    int unit, split = 0;
     {
-        const int nb = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
+        const int nb = SPLIT == 2 ? (int)gridDim.x : SPLIT == 1 ? g.nitems_launch * g.nsplit : g.nitems_launch;
         const int bid = blockIdx.x, xcd = bid & 7, loc = bid >> 3;
         const int q = nb >> 3, r = nb & 7;
-        int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        if (SPLIT) { split = u % g.nsplit; u /= g.nsplit; }
-        item = g.item_offset + u;
+        unit = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    const int h = item / nQ, qb = item - h * nQ;
-    const int q0 = qb * QB + wave * 32;
+    int sk_lo = 0, sk_hi = 0, seg = 0;
+    if (SPLIT == 2) {
+        const long long total = (long long)g.nitems_launch * ntiles_all;
+        sk_lo = (int)((long long)unit * total / (int)gridDim.x);
+        sk_hi = (int)((long long)(unit + 1) * total / (int)gridDim.x);
+        if (sk_lo >= sk_hi) return;
+    }
     const uint32_t HD2 = (uint32_t)g.H * 256u;                 // bytes of one K row (H * 128 bf16)
-
-    const int ntiles_all = g.Skv / KV_T;
-    int t_begin = 0, ntiles = ntiles_all;
-    if (SPLIT) {
+#pragma nounroll
+  for (;;) {
+    // the lane id is made opaque per segment: otherwise the compiler hoists the ~20 lane-dependent address registers out of the
+    // segment loop and, with v32-v159 / a0-a95 pinned by the asm block, parks them in a96+ - past the 256 registers a wave may own
+    int lane = tid & 63;
+    if (SPLIT == 2) asm volatile("" : "+v"(lane));
+    const int ql = lane & 31, half = lane >> 5;
+    int item, t_begin = 0, ntiles = ntiles_all;
+    if (SPLIT == 2) {
+        const int il = sk_lo / ntiles_all;
+        item = g.item_offset + il;
+        t_begin = sk_lo - il * ntiles_all;
+        ntiles = min(ntiles_all - t_begin, sk_hi - sk_lo);
+    } else if (SPLIT == 1) {
+        split = unit % g.nsplit;
+        item = g.item_offset + unit / g.nsplit;
         const int per = (ntiles_all + g.nsplit - 1) / g.nsplit;
         t_begin = split * per;
         ntiles = max(0, min(per, ntiles_all - t_begin));
+    } else {
+        item = g.item_offset + unit;
     }
+    const int h = item / nQ, qb = item - h * nQ;
+    const int q0 = qb * QB + wave * 32;
     float m_run = -1e30f, l_run = 0.f;
     if (ntiles > 0) {
         // per-lane relative LDS addresses of the fragments (same swizzles as attention_kernel)
@@ -397,22 +421,8 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
         const uint32_t wdst = __builtin_amdgcn_readfirstlane((uint32_t)wave * 2048u);
         uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) >> 1), rem = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) & 1u);
         const float sl2e = g.scale_log2e;
+        const uint64_t sl2e2 = ((uint64_t)__float_as_uint(sl2e) << 32) | __float_as_uint(sl2e);    // both halves: packed-fp32 operand
         uint32_t stmp, stmp2, sdst;
-#define RGN_ATTN_OPERANDS \
-                     : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k), \
-                       [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2), \
-                       [sdst] "=&s"(sdst) \
-                     : [krel0] "v"(krel[0]), [krel1] "v"(krel[1]), [krel2] "v"(krel[2]), [krel3] "v"(krel[3]), [krel4] "v"(krel[4]), \
-                       [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]), \
-                       [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]), \
-                       [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last), \
-                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e) \
-                     : RGN_ATTN_LOOP_CLOBBERS
-        if constexpr (AV == 1) asm volatile(RGN_ATTN_LOOP_ASM_V1 RGN_ATTN_OPERANDS);
-        else if constexpr (AV == 2) asm volatile(RGN_ATTN_LOOP_ASM_V2 RGN_ATTN_OPERANDS);
-        else if constexpr (AV == 3) asm volatile(RGN_ATTN_LOOP_ASM_V3 RGN_ATTN_OPERANDS);
-        else if constexpr (AV == 4) asm volatile(RGN_ATTN_LOOP_ASM_V4 RGN_ATTN_OPERANDS);
-        else
         asm volatile(RGN_ATTN_LOOP_ASM
                      : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k),
                        [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2),
@@ -421,14 +431,15 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
                        [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]),
                        [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]),
                        [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last),
-                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e)
+                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e), [sl2e2] "s"(sl2e2)
                      : RGN_ATTN_LOOP_CLOBBERS);
     }
     // O^T accumulator: a[db * 16 + r] (zero when this split piece had no tiles - but then the launch has none either)
     const float l_other = __shfl_xor(l_run, 32, 64);
     const float l_tot = l_run + l_other;
     if (SPLIT) {
-        float* base = g.ws + ((size_t)(item - g.item_offset) * g.nsplit + split) * (size_t)(QB * 130);
+        const size_t slot = SPLIT == 2 ? (size_t)unit * 2 + seg : (size_t)(item - g.item_offset) * g.nsplit + split;
+        float* base = g.ws + slot * (size_t)(QB * 130);
         float* orow = base + (size_t)(wave * 32 + ql) * 128;
         static_for<16>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;           // I = db * 4 + r4
@@ -441,7 +452,12 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
             base[QB * 128 + wave * 32 + ql] = m_run;
             base[QB * 129 + wave * 32 + ql] = l_tot;
         }
-        return;
+        if (SPLIT != 2) return;
+        sk_lo += ntiles;
+        ++seg;
+        if (sk_lo >= sk_hi) return;
+        __syncthreads();                    // every wave is out of the K/V ring before the next segment's prologue refills it
+        continue;
     }
     const float inv = 1.0f / l_tot;
     constexpr int OT_LD = 136;
@@ -465,6 +481,8 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
         const int qr2 = qb * QB + row;
         if (qr2 < g.Sq) *(uint4*)(g.O + (size_t)qr2 * g.ldo + h * 128 + c) = *(const uint4*)(ot + row * OT_LD + c);
     }
+    return;
+  }
 }
 
 // Merge the nsplit partial results of each split item: O = sum_s O_s 2^(m_s - m*) / sum_s l_s 2^(m_s - m*).
@@ -498,29 +516,63 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g
     *(uint4*)(g.O + (size_t)qr * g.ldo + h * 128 + c) = out;
 }
 
-template <bool SPLIT>
-static int launch_attention_asm(const AttnArgs& g, hipStream_t st) {
+// Stream-K merge: item u of the launch owns the flat steps [u * nt, (u + 1) * nt); run w of the G runs covers
+// [w * total / G, (w + 1) * total / G) and left its (first, second) segment in slots (2w, 2w + 1).
+template <int QB>
+__global__ __launch_bounds__(256) void attention_combine_sk_kernel(const AttnArgs g, int G) {
+    const int nQ = (g.Sq + QB - 1) / QB;
+    const int u = blockIdx.x / (QB / 16);
+    const int row = (blockIdx.x % (QB / 16)) * 16 + (threadIdx.x >> 4);
+    const int c = (threadIdx.x & 15) * 8;
+    const int item = g.item_offset + u;
+    const int h = item / nQ, qb = item - h * nQ;
+    const int qr = qb * QB + row;
+    if (qr >= g.Sq) return;
+    const int nt = g.Skv / KV_T;
+    const long long total = (long long)g.nitems_launch * nt;
+    const long long lo = (long long)u * nt, hi = lo + nt;
+    auto bound = [&](int w) { return (long long)w * total / G; };
+    int w0 = (int)(lo * G / total);
+    while (w0 + 1 < G && bound(w0 + 1) <= lo) ++w0;
+    while (w0 > 0 && bound(w0) > lo) --w0;
+    float mstar = -1e30f;
+    for (int w = w0; w < G && bound(w) < hi; ++w) {
+        if (bound(w + 1) <= bound(w)) continue;                                  // empty run
+        const int sg = ((int)(bound(w) / nt) == u) ? 0 : 1;
+        mstar = fmaxf(mstar, g.ws[((size_t)w * 2 + sg) * (size_t)(QB * 130) + QB * 128 + row]);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
+    for (int w = w0; w < G && bound(w) < hi; ++w) {
+        if (bound(w + 1) <= bound(w)) continue;
+        const int sg = ((int)(bound(w) / nt) == u) ? 0 : 1;
+        const float* b = g.ws + ((size_t)w * 2 + sg) * (size_t)(QB * 130);
+        const float wt = __builtin_amdgcn_exp2f(b[QB * 128 + row] - mstar);
+        l += b[QB * 129 + row] * wt;
+        const float4 x0 = *(const float4*)(b + (size_t)row * 128 + c), x1 = *(const float4*)(b + (size_t)row * 128 + c + 4);
+        acc[0] += x0.x * wt; acc[1] += x0.y * wt; acc[2] += x0.z * wt; acc[3] += x0.w * wt;
+        acc[4] += x1.x * wt; acc[5] += x1.y * wt; acc[6] += x1.z * wt; acc[7] += x1.w * wt;
+    }
+    const float inv = 1.0f / l;
+    uint4 out;
+    out.x = cvt_pk_bf16(acc[0] * inv, acc[1] * inv); out.y = cvt_pk_bf16(acc[2] * inv, acc[3] * inv);
+    out.z = cvt_pk_bf16(acc[4] * inv, acc[5] * inv); out.w = cvt_pk_bf16(acc[6] * inv, acc[7] * inv);
+    *(uint4*)(g.O + (size_t)qr * g.ldo + h * 128 + c) = out;
+}
+
+// nblocks: SPLIT 0 -> items, 1 -> items x nsplit, 2 -> the number of stream-K runs
+template <int SPLIT>
+static int launch_attention_asm(const AttnArgs& g, int nblocks, hipStream_t st) {
     constexpr int LDS = 5 * ATT_STAGE;                   // 160 KiB
     static bool attr[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (dev >= 0 && dev < 64) attr[dev] = true;
     }
-    const int nblocks = SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch;
     if (nblocks == 0) return 0;
-    // RGN_ATTN_ASMV (experiments): 1 / 2 = fragment prefetch distance 6 / 7; 3 / 4 = timing-only ablations (WRONG results)
-    static const int av = [] { const char* e = getenv("RGN_ATTN_ASMV"); return e ? atoi(e) : 0; }();
-#define RGN_LAUNCH_AV(N)                                                                                                   \
-    case N:                                                                                                                \
-        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT, N>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-        hipLaunchKernelGGL((attention_asm_kernel<SPLIT, N>), dim3(nblocks), dim3(512), LDS, st, g);                         \
-        break;
-    switch (av) {
-        RGN_LAUNCH_AV(1) RGN_LAUNCH_AV(2) RGN_LAUNCH_AV(3) RGN_LAUNCH_AV(4)
-        default: hipLaunchKernelGGL((attention_asm_kernel<SPLIT, 0>), dim3(nblocks), dim3(512), LDS, st, g);
-    }
+    hipLaunchKernelGGL((attention_asm_kernel<SPLIT>), dim3(nblocks), dim3(512), LDS, st, g);
     return check_launch("attention_asm_kernel");
 }
 
@@ -532,7 +584,8 @@ static bool attention_use_asm(const AttnArgs& g) {
 
 template <int NW, int NSTAGE, bool SPLIT>
 static int launch_attention(const AttnArgs& g, hipStream_t st) {
-    if (NW == 8 && attention_use_asm(g)) return launch_attention_asm<SPLIT>(g, st);
+    if (NW == 8 && attention_use_asm(g))
+        return launch_attention_asm<SPLIT ? 1 : 0>(g, SPLIT ? g.nitems_launch * g.nsplit : g.nitems_launch, st);
     constexpr int LDS = NSTAGE * ATT_STAGE;
     static bool attr[64] = {};          // per device (one process may drive several GPUs)
     int dev = 0;
@@ -557,18 +610,44 @@ static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, 
     const int nitems = g.H * ((g.Sq + QB - 1) / QB);
     const int ntiles = (g.Skv + KV_T - 1) / KV_T;
     int full = (nitems / slots) * slots, left = nitems - full, best = 1;
+    // Cost of the remainder launch in microseconds (8-wave kernels, head_dim 128, MI355X; tools/bench_kernels.py attn):
+    // a workgroup spends c_t per 256 x 64 KV tile and c_p per PIECE it starts (Q load, ring fill, fp32 partial dump, workgroup
+    // turn-over on a CU whose LDS one workgroup fills), the merge pass c_m.  Fits the measured region-step shapes within 5 %.
+    const float c_t = NW == 8 ? 1.69f : 0.95f, c_p = 10.7f, c_m = 8.0f;
+    float best_cost = (float)((left + slots - 1) / slots) * ((float)ntiles * c_t + c_p);
+    bool stream_k = false;
     if (left > 0 && ws != nullptr) {
-        float best_cost = (float)((left + slots - 1) / slots);
         for (int S = 2; S <= 8; ++S) {
             if (ntiles / S < 4) break;
             if ((size_t)left * S * QB * 130 * sizeof(float) > ws_bytes) break;
-            const float cost = (float)((left * S + slots - 1) / slots) / (float)S + 0.02f;
-            if (cost < best_cost - 1e-6f) { best_cost = cost; best = S; }
+            const float cost = (float)((left * S + slots - 1) / slots) * ((float)((ntiles + S - 1) / S) * c_t + c_p) + c_m;
+            if (cost < best_cost - 1e-3f) { best_cost = cost; best = S; }
+        }
+        // stream-K (asm kernel): `slots` equal runs of the flattened (item, KV tile) steps instead of S equal pieces per item -
+        // every CU gets the same number of steps whatever left / slots is, in ONE round, and the launch leaves at most
+        // left + slots partials instead of left x S; a run that crosses an item boundary pays the piece cost twice.
+        // RGN_ATTN_STREAMK=0: A/B switch back to the equal split; =2: stream-K wherever it is possible.
+        const char* sk_env = getenv("RGN_ATTN_STREAMK");
+        const long long steps = (long long)left * ntiles;
+        if (NW == 8 && (sk_env ? atoi(sk_env) : 1) && attention_use_asm(g) && left < slots && steps >= 8LL * slots &&
+            (size_t)slots * 2 * QB * 130 * sizeof(float) <= ws_bytes) {
+            const float cost = (float)((steps + slots - 1) / slots) * c_t + 2.0f * c_p + c_m;
+            if (cost < best_cost - 1e-3f || atoi(sk_env ? sk_env : "1") == 2) { best_cost = cost; stream_k = true; }   // 2: forced (tests)
         }
     }
     g.ws = (float*)ws;
     g.nsplit = 1;
     int rc = 0;
+    if (stream_k) {
+        if (full > 0) {
+            g.item_offset = 0; g.nitems_launch = full;
+            if ((rc = launch_attention<NW, NSTAGE, false>(g, st))) return rc;
+        }
+        g.item_offset = full; g.nitems_launch = left;
+        if ((rc = launch_attention_asm<2>(g, slots, st))) return rc;
+        hipLaunchKernelGGL((attention_combine_sk_kernel<QB>), dim3(left * (QB / 16)), dim3(256), 0, st, g, slots);
+        return check_launch("attention_combine_sk_kernel");
+    }
     if (best == 1) {
         g.item_offset = 0; g.nitems_launch = nitems;
         return launch_attention<NW, NSTAGE, false>(g, st);

@@ -907,10 +907,12 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
     if (!(asm_default || (v && v[0] == '3')) || (v && v[0] == '2')) asm4w = false;
     if (gg.p[0].wscale != nullptr) asm4w = false;
     const int b = use_big ? 256 : 128;
+    int ns256 = p256.nsplit;
+    if (const char* f = getenv("RGN_GEMM_NSPLIT")) { if (atoi(f) > 0 && ws != nullptr) ns256 = atoi(f); }   // measurement switch
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
     if (gg.nt == 0) return 0;
-    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, p256.nsplit, ws, st, asm4w)
+    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, ns256, ws, st, asm4w)
                    : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, split128(gg.nt, K, ws != nullptr, ws_bytes), ws, st);
 }
 

@@ -213,6 +213,48 @@ def test_attention_shapes(Sq, Skv, H):
     assert rel_err(out.cpu(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("Sq,Skv,H", [(717, 8704, 24), (1024, 8704, 24), (1137, 8576, 24), (2537, 8704, 24), (1408, 1600, 24),
+                                      (4608, 33280, 24)])
+def test_attention_stream_k_remainder(Sq, Skv, H, monkeypatch):
+    """Region-step query sets (Sq = T + K_e) leave fewer items than CUs: the (item, KV tile) steps are dealt out in equal
+    contiguous runs (stream-K), a run may cross one item boundary, attention_combine_sk_kernel merges the partials.  Must agree
+    with the unsplit schedule, with the equal-split schedule and with an fp32 reference (ragged last query block, a spiky key
+    late in the sequence so that partial maxima differ between runs)."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(Sq * 7 + Skv)
+    D = H * 128
+    q = bf(torch.randn(Sq, D, generator=g)).cuda()
+    k = bf(torch.randn(Skv, D, generator=g)).cuda()
+    v = bf(torch.randn(Skv, D, generator=g)).cuda()
+    k[Skv - 77] *= 5.0
+    k[3] *= 4.0
+    pad = ops.padded(Skv)
+    ks = torch.zeros(pad, D, dtype=torch.bfloat16, device="cuda")
+    ks[:Skv] = k
+    r = torch.arange(Skv)
+    pos = ((r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)).cuda()
+    vt = torch.zeros(D, pad, dtype=torch.bfloat16, device="cuda")
+    vt[:, pos] = v.T
+    outs = {}
+    for name, env in (("stream_k", {"RGN_ATTN_STREAMK": "2"}), ("auto", {}), ("equal_split", {"RGN_ATTN_STREAMK": "0"}), ("unsplit", {"RGN_ATTN_VARIANT": "8n"})):
+        with monkeypatch.context() as mp:
+            for key, val in env.items():
+                mp.setenv(key, val)                      # both switches are read per call
+            o = torch.empty_like(q)
+            ops.attention(q, ks, vt, o, Skv, H)
+            torch.cuda.synchronize()
+            outs[name] = o.cpu()
+    assert rel_err(outs["stream_k"], outs["unsplit"]) < 2e-3 and rel_err(outs["equal_split"], outs["unsplit"]) < 2e-3
+    assert torch.equal(outs["auto"], outs["stream_k"]) or torch.equal(outs["auto"], outs["equal_split"]) or \
+        torch.equal(outs["auto"], outs["unsplit"])
+    rows = torch.randperm(Sq, generator=g)[:192].sort().values.cuda()
+    qq = q[rows].float().view(-1, H, 128).transpose(0, 1)
+    kk, vv = k.float().view(Skv, H, 128).transpose(0, 1), v.float().view(Skv, H, 128).transpose(0, 1)
+    ref = F.scaled_dot_product_attention(qq[None], kk[None], vv[None])[0].transpose(0, 1).reshape(len(rows), D).cpu()
+    assert rel_err(outs["stream_k"][rows.cpu()], ref) < 1e-2
+    assert torch.isfinite(outs["stream_k"].float()).all()
+
+
 def test_gemm_round_aware_split_k_path():
     """Shapes whose tile count leaves a partial last round take the split-K remainder + reduce pass
     (proj_out of a FLUX single block: 408 tiles of 256x256 on 256 CUs).  Reference: fp32 matmul on the GPU."""

@@ -75,29 +75,45 @@ def bench_small():
              ("R ff2", 1024, 512, 3072, 12288), ("R5% ff2", 196, 512, 3072, 12288), ("R5% ff1", 196, 512, 12288, 3072),
              ("Qwen R ff2 T384", 1024, 384, 3072, 12288)]
     gated = os.environ.get("GEMM_EPI") == "gate"          # gated-residual epilogue (out-projections, ff2, proj_out) instead of bias
+    cold = os.environ.get("GEMM_COLD")                    # rotate over enough weight copies to overflow the Infinity Cache
+    only = os.environ.get("GEMM_ONLY")
+
+    def copies(W):
+        return [W] + ([W.clone() for _ in range(max(1, int(600e6 // (W.numel() * 2))))] if cold else [])
+    st = {"i": 0}
+
+    def nxt(Ws):
+        st["i"] = (st["i"] + 1) % len(Ws)
+        return Ws[st["i"]]
     for name, M, N, K in singles:
+        if only and only not in name:
+            continue
         A, W, b = rnd(M, K), rnd(N, K) * 0.05, rnd(N)
+        Ws = copies(W)
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         x, gate = rnd(M, N), rnd(N)
         for variant in VARIANTS:
             os.environ["RGN_GEMM_VARIANT"] = variant
             if gated:
-                med, best = timeit(lambda: ops.gemm(A, W, b, x, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=x))
+                med, best = timeit(lambda: ops.gemm(A, nxt(Ws), b, x, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=x))
             else:
-                med, best = timeit(lambda: ops.gemm(A, W, b, out))
+                med, best = timeit(lambda: ops.gemm(A, nxt(Ws), b, out))
             fl = 2.0 * M * N * K
             print(f"gemm[{variant:>4}] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  (ideal@1150 {fl/1150e6:6.1f} us)")
     for name, M0, M1, N, K in pairs:
+        if only and only not in name:
+            continue
         A0, A1, W0, W1, b = rnd(M0, K), rnd(M1, K), rnd(N, K) * 0.05, rnd(N, K) * 0.05, rnd(N)
+        W0s, W1s = copies(W0), copies(W1)
         o0, o1 = torch.empty(M0, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M1, N, dtype=torch.bfloat16, device="cuda")
         for variant in VARIANTS:
             os.environ["RGN_GEMM_VARIANT"] = variant
             if gated:
                 x0, x1, gate = rnd(M0, N), rnd(M1, N), rnd(N)
-                med, best = timeit(lambda: ops.gemm_pair(A0, W0, b, x0, A1, W1, b, x1, epilogue=ops.EPI_GATE_RESID, gate0=gate,
-                                                         resid0=x0, gate1=gate, resid1=x1))
+                med, best = timeit(lambda: ops.gemm_pair(A0, nxt(W0s), b, x0, A1, W1s[st["i"]], b, x1, epilogue=ops.EPI_GATE_RESID,
+                                                         gate0=gate, resid0=x0, gate1=gate, resid1=x1))
             else:
-                med, best = timeit(lambda: ops.gemm_pair(A0, W0, b, o0, A1, W1, b, o1))
+                med, best = timeit(lambda: ops.gemm_pair(A0, nxt(W0s), b, o0, A1, W1s[st["i"]], b, o1))
             fl = 2.0 * (M0 + M1) * N * K
             print(f"pair[{variant:>4}] {name:<18} M={M0}+{M1:<4} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  (ideal@1150 {fl/1150e6:6.1f} us)")
 

@@ -37,7 +37,7 @@ ACC = [TMP + 8 + i for i in range(4)]           # row-sum accumulators
 T_R = [TMP + 12 + i for i in range(4)]          # rescale temporaries
 K_TILE, STAGE, NSTAGE = 16384, 32768, 5
 LDS_END = STAGE * NSTAGE
-CFG = dict(D=4, novalu=False, noread=False, prio=False)      # generator knobs (main() emits several variants)
+CFG = dict(D=4, novalu=False, noread=False, prio=False, pkfma=False, pkadd=False)      # generator knobs (main() emits several variants)
 
 
 def v(n, w=1):
@@ -115,7 +115,52 @@ def pv_mfma(st, g):
 
 def exp_ops(p):
     """VALU of X(t) on S set p, in place: P = exp2(S * c - m); pf[k] = bf16x2(P[2k], P[2k+1]).  Ordered so that an op never
-    follows its producer closely."""
+    follows its producer closely.  ATTN_PKFMA=1 / ATTN_PKADD=1 (measurement builds): scale-and-shift / row sums on the
+    packed-fp32 instructions (two elements each; 35 VALU instructions fewer per tile) - measured SLOWER on MI355X (full step
+    1175 -> 1136 / 1148 / 1113 TFLOP/s with pk_fma / pk_add / both, same box), so the shipped loop keeps the scalar forms."""
+    b = S_BASE[p]
+    if not CFG["pkfma"]:
+        return exp_ops_scalar(p)
+    assert T_NEGM % 2 == 0 and b % 2 == 0
+    fma = lambda i: f"v_pk_fma_f32 {v(b + 2 * i, 2)}, {v(b + 2 * i, 2)}, %[sl2e2], {v(T_NEGM, 2)} op_sel_hi:[1,1,0]"
+    exp = lambda i: f"v_exp_f32 {v(b + i)}, {v(b + i)}"
+    cvt = lambda k: f"v_cvt_pk_bf16_f32 {v(PF + k)}, {v(b + 2 * k)}, {v(b + 2 * k + 1)}"
+    ops = [fma(i) for i in range(4)]
+    for i in range(32 + 12):
+        if i < 32:
+            ops.append(exp(i))
+        if i % 2 == 1 and (i + 8) // 2 < 16:
+            ops.append(fma((i + 8) // 2))              # elements i+7, i+8: needed by exp(i+7) six or more ops later
+        j = i - 10
+        if 0 <= j < 32 and j % 2 == 1:
+            ops.append(cvt(j // 2))
+    assert sum(o.startswith("v_cvt") for o in ops) == 16 and sum(o.startswith("v_pk_fma") for o in ops) == 16
+    # every element is scaled before its exp
+    seen = set()
+    for o in ops:
+        if o.startswith("v_pk_fma"):
+            r = int(o.split("v[")[1].split(":")[0])
+            seen |= {r, r + 1}
+        elif o.startswith("v_exp"):
+            assert int(o.split()[1].strip("v,")) in seen, o
+    return ops
+
+
+def rowsum_ops(p):
+    """l_run += sum of the 32 P values of this lane: two packed accumulators (4 running sums), 17 instructions"""
+    b = S_BASE[p]
+    if not CFG["pkadd"]:
+        return rowsum_ops_scalar(p)
+    assert ACC[0] % 2 == 0
+    acc = [v(ACC[0], 2), v(ACC[2], 2)]
+    ops = [f"v_pk_add_f32 {acc[0]}, {v(b, 2)}, {v(b + 2, 2)}", f"v_pk_add_f32 {acc[1]}, {v(b + 4, 2)}, {v(b + 6, 2)}"]
+    ops += [f"v_pk_add_f32 {acc[(i // 2) % 2]}, {acc[(i // 2) % 2]}, {v(b + i, 2)}" for i in range(8, 32, 2)]
+    ops += [f"v_pk_add_f32 {acc[0]}, {acc[0]}, {acc[1]}", f"v_add_f32 {v(ACC[0])}, {v(ACC[0])}, {v(ACC[1])}",
+            f"v_add_f32 %[l_run], %[l_run], {v(ACC[0])}"]
+    return ops
+
+
+def exp_ops_scalar(p):
     b = S_BASE[p]
     fma = lambda i: f"v_fma_f32 {v(b + i)}, {v(b + i)}, %[sl2e], {v(T_NEGM)}"
     exp = lambda i: f"v_exp_f32 {v(b + i)}, {v(b + i)}"
@@ -129,11 +174,10 @@ def exp_ops(p):
         j = i - 10
         if 0 <= j < 32 and j % 2 == 1:
             ops.append(cvt(j // 2))
-    assert sum(o.startswith("v_cvt") for o in ops) == 16
     return ops
 
 
-def rowsum_ops(p):
+def rowsum_ops_scalar(p):
     b = S_BASE[p]
     ops = [f"v_mov_b32 {v(ACC[i])}, {v(b + i)}" for i in range(4)]
     ops += [f"v_add_f32 {v(ACC[i % 4])}, {v(ACC[i % 4])}, {v(b + i)}" for i in range(4, 32)]
@@ -367,13 +411,16 @@ def emit():
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     out = os.path.join(here, "..", "regione_amd", "csrc", "attn_loop_asm.inc")
-    variants = [("RGN_ATTN_LOOP_ASM", dict(D=4)), ("RGN_ATTN_LOOP_ASM_V1", dict(D=6)), ("RGN_ATTN_LOOP_ASM_V2", dict(D=7)),
-                ("RGN_ATTN_LOOP_ASM_V3", dict(D=4, novalu=True)), ("RGN_ATTN_LOOP_ASM_V4", dict(D=4, noread=True))]
+    variants = [("RGN_ATTN_LOOP_ASM", dict(D=4))]
+    if os.environ.get("ATTN_GEN_EXPERIMENTS"):       # measurement builds only: prefetch distance 6 / 7, and two
+        # timing-only ablations that compute WRONG results (no softmax VALU / no LDS fragment reads)
+        variants += [("RGN_ATTN_LOOP_ASM_V1", dict(D=6)), ("RGN_ATTN_LOOP_ASM_V2", dict(D=7)),
+                     ("RGN_ATTN_LOOP_ASM_V3", dict(D=4, novalu=True)), ("RGN_ATTN_LOOP_ASM_V4", dict(D=4, noread=True))]
     with open(out, "w") as f:
         f.write("// GENERATED by tools/gen_attn_loop.py - do not edit.  Hand-scheduled KV loop of attention_asm_kernel.\n")
-        f.write("// V1 / V2: fragment prefetch distance 6 / 7; V3 / V4: timing-only ablations (no softmax VALU / no LDS reads).\n")
         for name, kw in variants:
-            CFG.update(dict(D=4, novalu=False, noread=False, prio=False))
+            CFG.update(dict(D=4, novalu=False, noread=False, prio=False, pkfma=os.environ.get("ATTN_PKFMA", "0") == "1",
+                            pkadd=os.environ.get("ATTN_PKADD", "0") == "1"))
             CFG.update(kw)
             lines = emit()
             n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
