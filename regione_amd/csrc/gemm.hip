@@ -145,6 +145,7 @@ struct GemmGroup {
     // MODE 2 sums the partials of each tile and runs the normal epilogue.
     int tile_offset, nt_launch, nsplit;
     float* ws;
+    int part4w;         // MODE 2: the partials were written by the hand-scheduled 4-wave geometry (its lane-linear layout)
     int dbg;            // timing experiments only (RGN_GEMM_DBG): bit 0 = skip the epilogue (results are garbage)
 };
 
@@ -423,6 +424,20 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
         return;
     }
     if (MODE == MODE_REDUCE && !ASM4W) {
+        if (BM == 256 && WN == 4 && gg.part4w) {
+            // the pieces ran on the hand-scheduled 4-wave geometry (wave tile 128 x 128, 64 fragments x 256 threads per tile):
+            // this wave's 128 x 64 tile is the left / right half of 4-wave wave (wm, wn / 2)'s - same lane layout per fragment
+            const float4* w = (const float4*)gg.ws + (size_t)unit * gg.nsplit * (size_t)(64 * 256) + (wm * 2 + (wn >> 1)) * 64 + lane;
+            for (int sp = 0; sp < gg.nsplit; ++sp) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float4 v = w[(size_t)(sp * 64 + i * 8 + (wn & 1) * 4 + j) * 256];
+                        acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
+                    }
+            }
+        } else {
         const float4* w = (const float4*)gg.ws + (size_t)unit * gg.nsplit * (size_t)(TM * TN * NT) + tid;
         for (int sp = 0; sp < gg.nsplit; ++sp) {
 #pragma unroll
@@ -432,6 +447,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                     const float4 v = w[(size_t)(sp * TM * TN + i * TN + j) * NT];
                     acc[i][j][0] += v.x; acc[i][j][1] += v.y; acc[i][j][2] += v.z; acc[i][j][3] += v.w;
                 }
+        }
         }
     }
 
@@ -508,17 +524,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM * BN >= 256 * 256) ? 1 : 2) void 
                             static_for<TM>([&](auto Ic) {
                                 constexpr int I = decltype(Ic)::value;
                                 float c[4];
-                                if constexpr (MODE == MODE_REDUCE) {
-                                    // sum of this fragment's split-K partials (same lane-linear layout as the dump)
-                                    const float4* w = (const float4*)gg.ws + (size_t)unit * gg.nsplit * (size_t)(TM * TN * NT) + tid;
-                                    c[0] = c[1] = c[2] = c[3] = 0.f;
-                                    for (int sp = 0; sp < gg.nsplit; ++sp) {
-                                        const float4 v = w[(size_t)(sp * TM * TN + I * TN + J) * NT];
-                                        c[0] += v.x; c[1] += v.y; c[2] += v.z; c[3] += v.w;
-                                    }
-                                } else {
-                                    agpr_read4<(I * TN + J) * 4>(c);
-                                }
+                                agpr_read4<(I * TN + J) * 4>(c);
                                 put(I, c);
                             });
                         }
@@ -775,29 +781,42 @@ static inline int tiles(int M, int N, int b) { return ((M + b - 1) / b) * ((N + 
 // CUs (fp32 fragment partials in `ws`, ~0.07 us of L2/MALL traffic per partial tile) and finished by
 // a reduce pass that owns the epilogue (~10 us for the two extra launches).
 // ------------------------------------------------------------------------------------------------
-struct GemmPlan { int nsplit; float cost_us; };
+struct GemmPlan { int nsplit; float cost_us; bool asm_pieces; };
 
-static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes) {
+static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes, bool asm4w) {
     const int slots = 256, nk = K / BK;
     const size_t tile_bytes = (size_t)256 * 256 * 4;
     const int full_rounds = nt / slots, left = nt - full_rounds * slots;
-    // FULL mode: 1.5 us per K step + 10 us prologue/epilogue per tile; PARTIAL mode (fp32 fragment dump instead
-    // of the epilogue): 1.45 us + 5 us.  Fits every FLUX shape of tools/bench_kernels.py within ~7 %.
-    const float full_cost = (float)full_rounds * ((float)nk * 1.5f + 10.0f);
-    GemmPlan p{1, full_cost + (left > 0 ? (float)nk * 1.5f + 10.0f : 0.0f)};
-    if (left == 0 || !can_split) return p;
+    // microseconds per K step of 64 and per tile (prologue + epilogue), tools/bench_kernels.py K sweeps:
+    //   8-wave compiler-scheduled: 1.5 + 10 (FULL), 1.45 + 5 (PARTIAL: fp32 fragment dump instead of the epilogue), two extra
+    //   launches (partial, reduce) ~10 and ~0.07 per partial tile of L2 / MALL traffic;
+    //   4-wave hand-scheduled: 1.25 + 9 (FULL), 1.25 + 6 per piece (PARTIAL); its reduce launch reads nsplit x 256 KiB per tile
+    //   (~2 per partial) and runs the epilogue (~8 with the launch gap).
+    const float ks = asm4w ? 1.25f : 1.5f, tile_us = asm4w ? 9.0f : 10.0f;
+    const float full_cost = (float)full_rounds * ((float)nk * ks + tile_us);
+    GemmPlan p{1, full_cost + (left > 0 ? (float)nk * ks + tile_us : 0.0f), false};
+    if (left == 0 || !can_split || ws_bytes == 0) return p;
     const float base = p.cost_us;
-    for (int S = 2; S <= 6; ++S) {
-        if (nk / S < 8) break;
+    static const int asm_split_on = [] { const char* e = getenv("RGN_GEMM_ASM_SPLIT"); return e ? atoi(e) : 1; }();
+    bool any_asm = false;
+    for (int S = 2; S <= 8; ++S) {
+        if (nk / S < 6) break;
         if ((size_t)left * S * tile_bytes > ws_bytes) break;
         const int blocks = left * S, rounds = (blocks + slots - 1) / slots;
         const float per = (float)((nk + S - 1) / S);
-        const float cost = full_cost + (float)rounds * (per * 1.45f + 5.0f) + 0.07f * (float)blocks + 10.0f;
-        if (cost < p.cost_us) { p.cost_us = cost; p.nsplit = S; }
+        // pieces on the hand-scheduled geometry where it applies (faster at every piece length measured, tools/probes/
+        // fixup_ab.sh: R proj_out 162 -> 137 us, R ff2 137 -> 115), else on the 8-wave one; the reduce pass is the 8-wave one
+        float cost;
+        const bool asm_pieces = asm4w && asm_split_on;
+        if (asm_pieces) cost = full_cost + (float)rounds * (per * 1.25f + 8.0f) + 2.0f * (float)S + 10.0f;
+        else if (S <= 6 && nk / S >= 8) cost = full_cost + (float)rounds * (per * 1.45f + 5.0f) + 0.07f * (float)blocks + 10.0f;
+        else continue;
+        if (cost < p.cost_us) { p.cost_us = cost; p.nsplit = S; p.asm_pieces = asm_pieces; any_asm = asm_pieces; }
     }
-    static const float min_gain = [] { const char* e = getenv("RGN_GEMM_SPLIT_MIN_US"); return e ? (float)atof(e) : 30.0f; }();
+    static const float min_gain = [] { const char* e = getenv("RGN_GEMM_SPLIT_MIN_US"); return e ? (float)atof(e) : -1.0f; }();
     static const float min_frac = [] { const char* e = getenv("RGN_GEMM_SPLIT_MIN_FRAC"); return e ? (float)atof(e) : 0.05f; }();
-    if (base - p.cost_us < fmaxf(min_gain, min_frac * base)) { p.nsplit = 1; p.cost_us = base; }   // not worth two extra launches
+    const float need = fmaxf(min_gain >= 0.f ? min_gain : (any_asm ? 8.0f : 30.0f), min_frac * base);
+    if (base - p.cost_us < need) { p.nsplit = 1; p.cost_us = base; p.asm_pieces = false; }   // not worth the extra launches / the partial traffic
     return p;
 }
 
@@ -845,7 +864,7 @@ static int launch_mode(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_
             const int per = (nk + gg.nsplit - 1) / gg.nsplit;
             nk = nk - (gg.nsplit - 1) * per;
         }
-        if constexpr (MODE == MODE_FULL) {
+        if constexpr (MODE != MODE_REDUCE) {
             if (asm4w && asmv == 1 && nk >= 4) return launch_gemm<256, 256, 2, 2, MODE, 1>(gg, epilogue, st);
             if (asm4w) return launch_gemm<256, 256, 2, 2, MODE, 0>(gg, epilogue, st);
         }
@@ -854,12 +873,14 @@ static int launch_mode(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_
 }
 
 template <int BM, int BN, int WM, int WN>
-static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, void* ws, hipStream_t st, bool asm4w = false) {
+static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, void* ws, hipStream_t st, bool asm4w = false,
+                         bool asm_pieces = false) {
     const int nt = gg.nt;
     const int full = (nt / slots) * slots, left = nt - full;
     const char* v = getenv("RGN_GEMM_SPLIT");
     if ((v && v[0] == '0') || left == 0) nsplit = 1;
     gg.ws = (float*)ws;
+    gg.part4w = 0;
     gg.nsplit = 1;
     static const int dbg = [] { const char* e = getenv("RGN_GEMM_DBG"); return e ? atoi(e) : 0; }();
     gg.dbg = dbg;
@@ -873,14 +894,15 @@ static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, voi
         if ((rc = launch_mode<BM, BN, WM, WN, MODE_FULL>(gg, epilogue, asm4w, st))) return rc;
     }
     gg.tile_offset = full; gg.nt_launch = left; gg.nsplit = nsplit;
-    // the split pieces of the asm geometry need >= 2 K tiles each (>= 4 for the ring variant, checked in launch_mode)
-    const int nk_all = gg.p[0].K / BK, per = (nk_all + nsplit - 1) / nsplit;
-    // the split remainder stays on the 8-wave geometry: a 4-wave reduce pass (64 fragments per thread, each the sum of
-    // nsplit dependent-latency loads) measured 1.5 - 3x slower than the 8-wave one (txt ff2 473 -> 155 TFLOP/s)
-    const bool asm_split = false;
-    (void)nk_all; (void)per;
+    const int nk_all = gg.p[0].K / BK, per = (nk_all + nsplit - 1) / nsplit, shortest = nk_all - (nsplit - 1) * per;
+    // hand-scheduled geometry for the pieces where the plan asks for it (long pieces; the asm K loop needs >= 2 K tiles in the
+    // shortest piece, >= 4 for the ring variant).  The reduce pass stays on the 8-wave geometry and reads that layout (an
+    // in-kernel finish by the last-arriving piece was measured and dropped).
+    // RGN_GEMM_ASM_SPLIT=0 (A/B switch, read by the planner): 8-wave pieces.
+    const bool asm_split = asm4w && asm_pieces && shortest >= 2;
+    gg.part4w = asm_split ? 1 : 0;
     if ((rc = launch_mode<BM, BN, WM, WN, MODE_PARTIAL>(gg, epilogue, asm_split, st))) return rc;
-    return launch_mode<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, asm_split, st);
+    return launch_mode<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, false, st);
 }
 
 static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_t ws_bytes, hipStream_t st) {
@@ -892,27 +914,35 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
         flops += 2.0 * gg.p[i].M * (double)gg.p[i].N * gg.p[i].K;
     }
     const int K = gg.p[0].K;
-    const GemmPlan p256 = plan256(big, K, ws != nullptr, ws_bytes);
-    const float e128 = estimate128(small_, K, flops);
-    // the model is coarse: leave the habitual choice (256x256 from ~200 tiles up) only for a clear predicted win
-    bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < 0.92f * e128);
     const char* v = getenv("RGN_GEMM_VARIANT");
-    if (v && v[0] == '1') use_big = false;
-    if (v && (v[0] == '2' || v[0] == '3')) use_big = true;
-    // hand-scheduled 4-wave K loop for the whole-K tiles: needs >= 2 K tiles and 32-bit operand offsets
+    // hand-scheduled 4-wave K loop for the 256x256 tiles: needs >= 2 K tiles and 32-bit operand offsets
     bool asm4w = K >= 2 * BK;
     for (int i = 0; i < nprob; ++i)
         asm4w = asm4w && (size_t)gg.p[i].M * gg.p[i].lda * 2 < ((size_t)1 << 32) && (size_t)gg.p[i].N * gg.p[i].ldw * 2 < ((size_t)1 << 32);
     static const int asm_default = [] { const char* e = getenv("RGN_GEMM_ASM"); return e ? atoi(e) : 1; }();   // RGN_GEMM_ASM=0: A/B switch
     if (!(asm_default || (v && v[0] == '3')) || (v && v[0] == '2')) asm4w = false;
     if (gg.p[0].wscale != nullptr) asm4w = false;
+    const GemmPlan p256 = plan256(big, K, ws != nullptr, ws_bytes, asm4w);
+    const float e128 = estimate128(small_, K, flops);
+    // the model is coarse: leave the habitual choice (256x256 from ~200 tiles up) only for a clear predicted win
+    bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < 0.92f * e128);
+    if (v && v[0] == '1') use_big = false;
+    if (v && (v[0] == '2' || v[0] == '3')) use_big = true;
     const int b = use_big ? 256 : 128;
     int ns256 = p256.nsplit;
-    if (const char* f = getenv("RGN_GEMM_NSPLIT")) { if (atoi(f) > 0 && ws != nullptr) ns256 = atoi(f); }   // measurement switch
+    bool asm_pieces = p256.asm_pieces;
+    if (const char* f = getenv("RGN_GEMM_NSPLIT")) {          // measurement / test switch: piece count forced, asm pieces unless switched off
+        if (atoi(f) > 0 && ws != nullptr) {
+            ns256 = atoi(f);
+            while (ns256 > 1 && (size_t)(big % 256) * ns256 * ((size_t)256 * 256 * 4) > ws_bytes) --ns256;      // must fit the workspace
+            const char* e = getenv("RGN_GEMM_ASM_SPLIT");
+            asm_pieces = asm4w && !(e && atoi(e) == 0);
+        }
+    }
     gg.nt0 = tiles(gg.p[0].M, gg.p[0].N, b);
     gg.nt = gg.nt0 + (nprob > 1 ? tiles(gg.p[1].M, gg.p[1].N, b) : 0);
     if (gg.nt == 0) return 0;
-    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, ns256, ws, st, asm4w)
+    return use_big ? gemm_schedule<256, 256, 2, 4>(gg, epilogue, 256, ns256, ws, st, asm4w, asm_pieces)
                    : gemm_schedule<128, 128, 2, 2>(gg, epilogue, 512, split128(gg.nt, K, ws != nullptr, ws_bytes), ws, st);
 }
 

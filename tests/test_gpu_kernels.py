@@ -439,6 +439,48 @@ def test_gemm_qkv_fp16_roundtrip_option():
     assert float((k0.float() - k1.float()).abs().max()) <= 2 ** -5 * float(k0.float().abs().max())
 
 
+@pytest.mark.parametrize("nsplit", [2, 3, 5])
+@pytest.mark.parametrize("shape,epi", [((1536, 3072, 15360), "gate"), ((8704, 3072, 15360), "gate"), ((708, 3072, 12288), "bias"),
+                                       (((1024, 512), 3072, 12288), "gate"), (((196, 512), 12288, 3072), "gelu")])
+def test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled(shape, epi, nsplit, monkeypatch):
+    """Remainder tiles are cut along K: every piece runs the hand-scheduled K loop over its K range and dumps fp32 fragments,
+    a reduce launch of the same geometry sums them in index order (batched loads into the AGPR accumulators) and runs the
+    epilogue.  Same piece count -> bit-identical to the 8-wave partial + reduce launches, launch after launch, and within
+    rounding of the unsplit result."""
+    from regione_amd import ops
+    Ms, N, K = shape
+    pair = isinstance(Ms, tuple)
+    g = torch.Generator().manual_seed(N + K + nsplit)
+    mk = lambda M: bf(torch.randn(M, K, generator=g)).cuda()
+    As = [mk(M) for M in (Ms if pair else (Ms,))]
+    Ws = [bf(torch.randn(N, K, generator=g) * 0.05).cuda() for _ in As]
+    b = bf(torch.randn(N, generator=g)).cuda()
+    gate = bf(torch.randn(N, generator=g)).cuda()
+    xs = [bf(torch.randn(A.shape[0], N, generator=g)).cuda() for A in As]
+    E = {"gate": ops.EPI_GATE_RESID, "gelu": ops.EPI_GELU, "bias": ops.EPI_BIAS}[epi]
+
+    def run():
+        outs = [x.clone() for x in xs]
+        if pair:
+            kw = dict(gate0=gate, resid0=outs[0], gate1=gate, resid1=outs[1]) if epi == "gate" else {}
+            ops.gemm_pair(As[0], Ws[0], b, outs[0], As[1], Ws[1], b, outs[1], epilogue=E, **kw)
+        else:
+            kw = dict(gate=gate, resid=outs[0]) if epi == "gate" else {}
+            ops.gemm(As[0], Ws[0], b, outs[0], epilogue=E, **kw)
+        torch.cuda.synchronize()
+        return torch.cat(outs)
+    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
+    monkeypatch.setenv("RGN_GEMM_NSPLIT", str(nsplit))
+    fix = [run() for _ in range(3)]
+    assert torch.equal(fix[0], fix[1]) and torch.equal(fix[0], fix[2])
+    monkeypatch.setenv("RGN_GEMM_VARIANT", "2")                   # 8-wave geometry for the pieces and the reduce pass
+    red = run()
+    assert torch.equal(fix[0], red), float((fix[0].float() - red.float()).abs().max())
+    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")
+    whole = run()
+    assert rel_err(fix[0].cpu(), whole.cpu()) < 2e-3
+
+
 @pytest.mark.parametrize("asmv", ["0", "1"])
 @pytest.mark.parametrize("M,N,K,epi", [(8704, 3072, 3072, "bias"), (1536, 21504, 3072, "gelu"), (700, 3072, 15360, "gate"),
                                        (513, 520, 128, "bias"), (8192, 512, 192, "gelu"), (300, 704, 256, "gate"),
@@ -464,6 +506,9 @@ def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, e
     b = bf(torch.randn(N, generator=g)).cuda()
     gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
     outs = []
+    # whole-K tiles only: the two geometries' launch planners may cut a remainder into different numbers of K pieces
+    # (split remainders at EQUAL piece counts: test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled)
+    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")
     for variant in ("2", "3"):
         monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
         if epi == "gate":
