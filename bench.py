@@ -443,7 +443,7 @@ def main():
     result["gemm_shapes"] = timer.shape_table()
     if "attention_kernel" in ksum:
         k = ksum["attention_kernel"]
-        result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_kernel", "achieved": k["achieved_tflops"],
+        result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_asm_kernel (+ attention_kernel for ragged KV lengths)", "achieved": k["achieved_tflops"],
                                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
                                         "traffic": pmc.get("attention_kernel", {}).get("traffic_bytes_per_launch"),
                                         "launches": k["launches"], "avg_launch_us": k["avg_us"],

@@ -133,7 +133,7 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
             should_cache, ratio = avd_decide(MANAGER, avd, i, timesteps)
             if should_cache:                                                    # inplace.py:315-318
                 first_hit = cache.shape[1] != latents.shape[1]
-                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
+                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None, MANAGER.avd_round_ratio)
                 if first_hit:
                     cache = ids_gather(cache, MANAGER.edited_ids)
             else:

@@ -94,6 +94,11 @@ class FluxKontextManager:
         if self.gamma is not None:
             self.gamma = torch.as_tensor(self.gamma, dtype=torch.float16).cpu()
             assert self.gamma.numel() == args["num_inference_steps"] - 1, "gamma must have num_inference_steps - 1 entries"
+        # Extension `gpu_eager_scalars` (default False = what the CPU-generated fixtures pin): torch's DEVICE kernels cast a
+        # 0-dim fp32 tensor operand to the bf16 of the other operand before `cache * ratio` (inplace.py:318), its CPU kernels
+        # keep the fp32 scalar.  True reproduces the reference as it runs on a GPU (cache-served velocities differ by up to
+        # 2^-9 relative between the two); the Euler update already follows the device behaviour on both (quirk A-2).
+        self.avd_round_ratio = bool(args.get("gpu_eager_scalars", False))
         self.inference_step = args["num_inference_steps"]
         self.warmup_step = args["warmup_step"]
         self.post_step = args["post_step"]

@@ -91,7 +91,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
             should_cache, ratio = fk.avd_decide(MANAGER, avd, i, timesteps, gamma)
             if should_cache:
                 first_hit = cache.shape[1] != latents.shape[1]
-                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None)
+                noise_pred = TO.R.avd_apply(cache, float(ratio), MANAGER.edited_ids if first_hit else None, MANAGER.avd_round_ratio)
                 if first_hit:
                     cache = ids_gather(cache, MANAGER.edited_ids)
             else:

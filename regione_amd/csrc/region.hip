@@ -254,17 +254,26 @@ __global__ __launch_bounds__(256) void cfg_combine_kernel(const T* __restrict__ 
     const float p = ld_as_f32<T>(pos, i), n = ld_as_f32<T>(neg, i);
     const float d = rnd<T>(__fsub_rn(p, n));                       // (pos - neg) in the tensor dtype
     float sd = rnd<T>(__fmul_rn(scale, d));                        // python-float scale: fp32 opmath, one rounding
+    // torch.norm(x, dim=-1) on the CPU: bf16 rows reduce as the xor butterfly (= wave_sum), fp32 rows as 8 FMA lanes added
+    // in order (row_sumsq_torch_f32) - the same trees the partition's cosine uses
+    auto row_norm = [&](float x) {
+        if constexpr (sizeof(T) == 2) return rnd<T>(sqrtf(wave_sum(__fmul_rn(x, x))));
+        else return sqrtf(row_sumsq_torch_f32(x, lane));
+    };
     if (mode == 1) {
-        float nrm = rnd<T>(sqrtf(wave_sum(__fmul_rn(d, d))));      // torch.norm(diff, dim=2, keepdim=True)
+        float nrm = row_norm(d);                                   // torch.norm(diff, dim=2, keepdim=True)
         float f = nrm;
-        if (nrm > 1.0f) f = rnd<T>(powf(nrm, power));
+        // torch.pow(tensor, python_float): the exponent is cast to the TENSOR dtype first (0.4 -> bf16 0.400390625)
+        // (pow evaluated in double and rounded once: torch's CPU kernel is Sleef's 1-ulp powf, which a correctly rounded value
+        // matches far more often than the device powf does; exact for bf16 tensors after their rounding)
+        if (nrm > 1.0f) f = rnd<T>((float)pow((double)nrm, (double)rnd<T>(power)));
         else if (nrm < 1.0f) f = 1.0f;
         sd = rnd<T>(sd / f);
     }
     float c = rnd<T>(__fadd_rn(n, sd));
     if (mode == 2) {
-        const float cn = rnd<T>(sqrtf(wave_sum(__fmul_rn(p, p))));
-        const float nn = rnd<T>(sqrtf(wave_sum(__fmul_rn(c, c))));
+        const float cn = row_norm(p);
+        const float nn = row_norm(c);
         c = rnd<T>(__fmul_rn(c, rnd<T>(cn / nn)));
     }
     st_from_f32<T>(out, i, c);

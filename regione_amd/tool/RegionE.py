@@ -108,7 +108,7 @@ class RegionEHelper(object):
         self._engine()._cfg_pair = pair
 
     def set_params(self, num_inference_steps=28, warmup_step=None, post_step=None, refresh_step=None, threshold=None,
-                   cache_threshold=None, erosion_dilation=None, strict_reference=None, gamma=None):
+                   cache_threshold=None, erosion_dilation=None, strict_reference=None, gamma=None, gpu_eager_scalars=None):
         # reference: 28 steps only (tool/RegionE.py:44).  Extension: `gamma` = N-1 fitted decay factors (list / tensor,
         # e.g. from tools/fit_gamma.py) or "resample" (the family's 27-entry table linearly re-sampled to N-1 entries,
         # SURVEY.md section 8d config 5) lifts the restriction.
@@ -126,4 +126,5 @@ class RegionEHelper(object):
         if cache_threshold is not None: self.config['cache_threshold'] = cache_threshold
         if erosion_dilation is not None: self.config['erosion_dilation'] = erosion_dilation
         if strict_reference is not None: self.config['strict_reference'] = strict_reference   # extension, see FluxKontext/inplace.py
+        if gpu_eager_scalars is not None: self.config['gpu_eager_scalars'] = gpu_eager_scalars   # extension, see FluxKontext/utils.py:set_parameters
         print(f"RegionEHelper: set_params {self.config}")

@@ -165,7 +165,7 @@ def test_cfg_combine_modes(dtype):
     pos = torch.randn(1, K, 64, generator=gen).to(dtype)
     neg = (pos.float() + 0.3 * torch.randn(1, K, 64, generator=gen)).to(dtype)
     neg[0, :100] = pos[0, :100] + (0.01 * torch.randn(100, 64, generator=gen)).to(dtype)     # ||diff|| < 1 rows
-    s = 6.0
+    s = 3.7 if dtype == torch.float32 else 6.0          # a scale that is not exactly representable in fp32 as well
     ref0 = neg + s * (pos - neg)                                                   # FluxKontext/inplace.py:364
     out0 = ops.cfg_combine(pos.cuda(), neg.cuda(), s, ops.CFG_PLAIN).cpu()
     assert torch.equal(out0, ref0)
@@ -174,9 +174,12 @@ def test_cfg_combine_modes(dtype):
     f = torch.where(dn > 1.0, torch.pow(dn, 0.4), torch.where(dn < 1.0, torch.ones_like(dn), dn))
     ref1 = neg + s * (pos - neg) / f
     out1 = ops.cfg_combine(pos.cuda(), neg.cuda(), s, ops.CFG_STEP1X_RESCALE, 0.4).cpu()
-    tol = 2 ** -7 if dtype == torch.bfloat16 else 1e-5                              # row-norm reduction order differs
-    assert float((out1.float() - ref1.float()).abs().max()) <= tol * float(ref1.float().abs().max())
+    if dtype == torch.bfloat16:       # torch-CPU's row-norm tree and its bf16 cast of the pow exponent: bit for bit
+        assert torch.equal(out1, ref1)
+    else:                             # fp32: torch's pow is Sleef's 1-ulp powf; the kernel rounds a double pow once
+        assert float((out1 - ref1).abs().max()) <= 1e-6 * float(ref1.abs().max())
+        assert float((out1 != ref1).any(-1).float().mean()) < 0.10
     comb = neg + s * (pos - neg)                                                    # QwenImageEdit/inplace.py:401-405
     ref2 = comb * (torch.norm(pos, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
     out2 = ops.cfg_combine(pos.cuda(), neg.cuda(), s, ops.CFG_QWEN_NORM).cpu()
-    assert float((out2.float() - ref2.float()).abs().max()) <= tol * float(ref2.float().abs().max())
+    assert torch.equal(out2, ref2)                                                  # both dtypes: bit for bit

@@ -30,7 +30,7 @@ def cpu_ops(monkeypatch):
             a = torch.where(mask.bool()[None, :, None], a, b)
         return a.to(v.dtype)
 
-    def avd(cache, ratio, ids=None):
+    def avd(cache, ratio, ids=None, round_ratio=False):
         c = O.ids_gather(cache, ids) if ids is not None else cache
         return c * torch.tensor(ratio)
 

@@ -32,7 +32,7 @@ def main():
     # one row per (dispatch, counter): the counter's instances (XCC / SE dimensions) summed, and how many there were
     agg = {}
     for name, _, counter, rows, total in c.execute(q):
-        if "gemm_bf16_kernel" in name or "attention_kernel" in name:
+        if "gemm_bf16_kernel" in name or "attention_kernel" in name or "attention_asm_kernel" in name:
             short = name.split("(")[0].replace("void rgn::", "")
             for k in (short, "ALL " + ("gemm_bf16_kernel" if "gemm" in name else "attention_kernel")):
                 d = agg.setdefault(k, {}).setdefault(counter, [0, 0.0, 0])

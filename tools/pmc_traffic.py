@@ -29,7 +29,10 @@ def per_kernel(db):
          f"join {disp} d on e.{key} = d.{dkey} join {sym} s on d.kernel_id = s.id group by s.kernel_name, p.name")
     out = {}
     for name, counter, n, total in c.execute(q):
-        k = "gemm_bf16_kernel" if "gemm_bf16_kernel" in name else "attention_kernel" if "attention_kernel" in name else None
+        # attention_asm_kernel (hand-scheduled loop) and attention_kernel (ragged KV lengths) count as one kernel family;
+        # the small merge kernels (attention_combine*) are left out
+        k = ("gemm_bf16_kernel" if "gemm_bf16_kernel" in name else
+             "attention_kernel" if ("attention_kernel" in name or "attention_asm_kernel" in name) else None)
         if k:
             d = out.setdefault(k, {}).setdefault(counter, [0, 0.0])
             d[0] += n

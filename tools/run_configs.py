@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Full-size runs of the BASELINE.json configurations that are NOT the bench line (GPU box only).
 
-    python tools/run_configs.py [flux_sweep] [flux_cfg] [step1x_512] [step1x_v1p2_2048] [qwen_1024] [--out FILE]
+    python tools/run_configs.py [flux_sweep] [flux_cfg] [step1x_512] [step1x_v1p2_2048] [step1x_v1p2_2048_50] [step1x_v1p2_2048_50_fp8] [qwen_1024] [--out FILE]
 
 Each case builds the family's engine at its public dimensions with synthetic weights, enables RegionE
 through RegionEHelper exactly like a user would, fixes the edited region by construction (the same
@@ -60,7 +60,7 @@ def make_box(h_tok, w_tok, frac):
 
 
 def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, timed_edits=1, vanilla_runs=2, steps=28,
-             helper_kw=None):
+             helper_kw=None, fp8=False):
     from regione_amd.harness import flux as HF, step1x as HS, qwen as HQ
     from oracle import regione_oracle as O      # checker only: derive_schedule / psnr
     h_tok = w_tok = size // 16
@@ -81,6 +81,8 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
         pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, device).load_state_dict_stream(weights_stream(cfg, device, 42)))
         defaults = {}
         fam_key = "qwen"
+    if fp8:                                  # OCP e4m3fn block-GEMM weights, per-output-channel scales
+        pipe.transformer.quantize_fp8_()
     torch.cuda.synchronize()
     Tn = Tn or T
     lat, img, prompt, pooled = synth.make_edit_inputs(h_tok, w_tok, T, cfg, seed=110, dtype=torch.bfloat16)
@@ -138,7 +140,7 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
                finite=bool(torch.isfinite(out.float()).all()), steps=steps, regione_edit_s=tr_s, regione_steps_per_s=steps / tr_s,
                full_token_edit_s=tv, full_token_steps_per_s=steps / tv, speedup=tv / tr_s,
                psnr_vs_full_token_db=float(O.psnr(out.cpu(), van.cpu())), cfg_scale=cfg_scale,
-               peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)
+               peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, weights="fp8 e4m3fn + per-channel scale" if fp8 else "bf16")
     helper.disable()
     del pipe, helper
     torch.cuda.empty_cache()
@@ -150,20 +152,25 @@ CASES = {
     "flux_sweep": [("flux_1024_ke%02d" % int(f * 100), "flux", 1024, f, {}) for f in (0.05, 0.15, 0.25, 0.50)],
     "flux_cfg": [("flux_1024_truecfg6_ke25 (configs[3], one rank's image)", "flux", 1024, 0.25, dict(cfg_scale=6.0))],
     "step1x_512": [("step1x_v1p1_512_cfg6 (configs[0] on the GPU)", "step1x", 512, 0.25, dict(cfg_scale=6.0))],
-    "step1x_v1p2_2048": [("step1x_v1p2_2048_cfg6 bf16 28 steps (configs[4] shape; fp8 / 50 steps are later rows)", "step1x_v1p2",
+    "step1x_v1p2_2048": [("step1x_v1p2_2048_cfg6 bf16 28 steps (configs[4] shape at 28 steps)", "step1x_v1p2",
                           2048, 0.25, dict(cfg_scale=6.0, Tn=384, vanilla_runs=1))],
-    "step1x_v1p2_2048_50": [("step1x_v1p2_2048_cfg6 bf16 50 steps, gamma re-sampled to 49 entries (configs[4]; fp8 weights are a later row)",
+    "step1x_v1p2_2048_50": [("step1x_v1p2_2048_cfg6 bf16 50 steps, gamma re-sampled to 49 entries (configs[4] on bf16 weights)",
                              "step1x_v1p2", 2048, 0.25,
                              dict(cfg_scale=6.0, Tn=384, vanilla_runs=1, steps=50,
                                   helper_kw=dict(num_inference_steps=50, gamma="resample", warmup_step=10, post_step=4,
                                                  refresh_step="28", cache_threshold=0.02)))],
+    "step1x_v1p2_2048_50_fp8": [("step1x_v1p2_2048_cfg6 fp8 weights 50 steps, gamma re-sampled to 49 entries (configs[4])",
+                                 "step1x_v1p2", 2048, 0.25,
+                                 dict(cfg_scale=6.0, Tn=384, vanilla_runs=1, steps=50, fp8=True,
+                                      helper_kw=dict(num_inference_steps=50, gamma="resample", warmup_step=10, post_step=4,
+                                                     refresh_step="28", cache_threshold=0.02)))],
     "qwen_1024": [("qwen_image_edit_1024_cfg4 (configs[2])", "qwen", 1024, 0.25, dict(cfg_scale=4.0, Tn=384))],
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=[c for c in CASES if c != "step1x_v1p2_2048_50"])
+    ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("step1x_v1p2_2048_50")])
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     device = torch.device("cuda", 0)
