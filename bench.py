@@ -410,8 +410,10 @@ def main():
         "ms_per_denoising_step": 1e3 * edit_s / N_STEPS,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"FLUX.1-Kontext-dev {args.size}x{args.size} 28-step RegionE edit, warmup=6 post=2 refresh=16 "
-                               f"thresh=0.88 cache_thresh=0.04, L=L_c={L}, T={T}, K_e={K_e} ({100.0 * K_e / L:.1f}% edited by "
-                               f"construction), plan {kinds}" + (f", true CFG {args.true_cfg} (two forwards per computed step)"
+                               f"thresh=0.88 cache_thresh=0.04, L=L_c={L}, T={T}, " +
+                               (f"K_e={K_e} ({100.0 * K_e / L:.1f}% edited by construction)" if per_rank is None else
+                                "K_e per rank: " + "/".join(str(r["K_e"]) for r in per_rank) + " (see per_rank)") +
+                               f", plan {kinds}" + (f", true CFG {args.true_cfg} (two forwards per computed step)"
                                                                   if args.true_cfg > 1 else ""),
                    "images_per_gpu": 1, "parallelism": f"image-sharded x{world}",
                    "params_billion": round(sum(int(torch.tensor(s).prod()) for s in synth.flux_param_shapes(cfg).values()) / 1e9, 2)},

@@ -103,3 +103,25 @@ def test_qwen_1024_full_size_plan_and_partition(golden):
     assert torch.isfinite(out.float()).all() and out.shape == (1, L, 64)
     del pipe
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("extra", [[], ["--true-cfg", "6.0"]])
+def test_bench_two_ranks_share_the_gpu(extra):
+    """bench.py's N > 1 path on a one-GPU box: two ranks (gloo, both on cuda:0, toy trunk) launched exactly like the driver
+    launches N ranks.  One JSON line from rank 0; per-rank K_e cycles 5 % / 15 %; `--true-cfg 6.0` = BASELINE configs[3]."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + (os.getpid() % 400) + (7 if extra else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--toy", "--share-gpu",
+           "--dist-backend", "gloo", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                               # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["unit"] == "steps/s"
+    assert [p["rank"] for p in d["per_rank"]] == [0, 1] and [p["edit_frac"] for p in d["per_rank"]] == [0.05, 0.15]
+    assert all(p["edit_s"] > 0 for p in d["per_rank"]) and d["per_rank"][0]["K_e"] < d["per_rank"][1]["K_e"]
+    assert ("true CFG 6.0" in d["config"]["workload"]) == bool(extra)
+    assert abs(d["value"] - 28 * 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
