@@ -58,7 +58,8 @@ struct GemmArgs {
     int lda, ldw, ldc;
     int M, N, K;
     int gelu_from_col;
-    const float* wscale;         // fp8 (OCP e4m3) weights: per-output-channel scale, applied to the fp32 accumulator; else nullptr
+    const float* wscale;         // per-output-channel scale, applied to the fp32 accumulator (fp8 weights); else nullptr
+    int w8;                      // W is OCP e4m3fn bytes (ldw in bytes); 0 = bf16 (also: fp8 weights widened into the workspace)
 };
 
 constexpr int BK = 64;
@@ -852,7 +853,7 @@ static float estimate128(int nt, int K, double flops) {
 // PARTIAL and REDUCE launches must use the SAME geometry: the partial fragments are stored lane-linear)
 template <int BM, int BN, int WM, int WN, int MODE>
 static int launch_mode(const GemmGroup& gg, int epilogue, bool asm4w, hipStream_t st) {
-    if (gg.p[0].wscale != nullptr) {                  // fp8 weights: compiler-scheduled geometries, AV = 8
+    if (gg.p[0].w8) {                                 // fp8 W tiles: compiler-scheduled geometries, AV = 8
         if constexpr (MODE == MODE_REDUCE) return launch_gemm<BM, BN, WM, WN, MODE>(gg, epilogue, st);   // W is not touched
         else return launch_gemm<BM, BN, WM, WN, MODE, 8>(gg, epilogue, st);
     }
@@ -905,7 +906,56 @@ static int gemm_schedule(GemmGroup& gg, int epilogue, int slots, int nsplit, voi
     return launch_mode<BM, BN, WM, WN, MODE_REDUCE>(gg, epilogue, false, st);
 }
 
+// fp8 (e4m3fn) -> bf16, exact (every e4m3 value is a bf16 value): 16 bytes in, 32 bytes out per thread and step
+__global__ __launch_bounds__(256) void widen_w8_kernel(const uint8_t* __restrict__ src, uint16_t* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+        const uint4 raw = ((const uint4*)src)[i];
+        const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+        uint32_t o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bf2_t lo = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[k], 1.0f, false);
+            const bf2_t hi = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[k], 1.0f, true);
+            o[2 * k] = *(const uint32_t*)&lo;
+            o[2 * k + 1] = *(const uint32_t*)&hi;
+        }
+        ((uint4*)dst)[2 * i] = make_uint4(o[0], o[1], o[2], o[3]);
+        ((uint4*)dst)[2 * i + 1] = make_uint4(o[4], o[5], o[6], o[7]);
+    }
+}
+
+// Large-M problems on fp8 weights: the GEMM is MFMA-bound whatever the weight format (bf16 activations -> bf16 MFMA), and the
+// hand-scheduled bf16 loop is ~15 % faster than the fp8-tile kernel, so the weight matrix is widened ONCE per call into the
+// tail of the caller's workspace (exact conversion, N x K x 3 bytes of traffic = ~3 % of such a GEMM's time) and the bf16
+// path runs on it; the per-channel scale still multiplies the fp32 accumulator in the epilogue, so the result is
+// bit-identical to the fp8-tile kernel's.  Weights stay fp8 in HBM.  RGN_W8_WIDEN_MIN_M (default 2048 rows in total; 0 = never).
+static int widen_w8(GemmGroup& gg, int nprob, void* ws, size_t& ws_bytes, hipStream_t st) {
+    const char* mm = getenv("RGN_W8_WIDEN_MIN_M");
+    const int min_m = mm ? atoi(mm) : 2048;
+    if (!gg.p[0].w8 || min_m <= 0 || ws == nullptr) return 0;
+    int m = 0;
+    size_t need = 0;
+    for (int i = 0; i < nprob; ++i) {
+        m += gg.p[i].M;
+        if (gg.p[i].ldw != gg.p[i].K || (gg.p[i].K % 16)) return 0;        // contiguous rows only
+        need += ((size_t)gg.p[i].N * gg.p[i].K * 2 + 255) & ~(size_t)255;
+    }
+    if (m < min_m || need + ((size_t)64 << 20) > ws_bytes) return 0;         // keep >= 64 MiB for split-K partials
+    uint8_t* dst = (uint8_t*)ws + ws_bytes - need;
+    ws_bytes -= need;
+    for (int i = 0; i < nprob; ++i) {
+        const size_t n16 = (size_t)gg.p[i].N * gg.p[i].K / 16;
+        hipLaunchKernelGGL(widen_w8_kernel, dim3((unsigned)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096)), dim3(256), 0, st,
+                           (const uint8_t*)gg.p[i].W, (uint16_t*)dst, n16);
+        gg.p[i].W = (const uint16_t*)dst;
+        gg.p[i].w8 = 0;
+        dst += ((size_t)gg.p[i].N * gg.p[i].K * 2 + 255) & ~(size_t)255;
+    }
+    return check_launch("widen_w8_kernel");
+}
+
 static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (int rc = widen_w8(gg, nprob, ws, ws_bytes, st)) return rc;
     int big = 0, small_ = 0;
     double flops = 0.0;
     for (int i = 0; i < nprob; ++i) {
@@ -921,7 +971,7 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
         asm4w = asm4w && (size_t)gg.p[i].M * gg.p[i].lda * 2 < ((size_t)1 << 32) && (size_t)gg.p[i].N * gg.p[i].ldw * 2 < ((size_t)1 << 32);
     static const int asm_default = [] { const char* e = getenv("RGN_GEMM_ASM"); return e ? atoi(e) : 1; }();   // RGN_GEMM_ASM=0: A/B switch
     if (!(asm_default || (v && v[0] == '3')) || (v && v[0] == '2')) asm4w = false;
-    if (gg.p[0].wscale != nullptr) asm4w = false;
+    if (gg.p[0].w8) asm4w = false;
     const GemmPlan p256 = plan256(big, K, ws != nullptr, ws_bytes, asm4w);
     const float e128 = estimate128(small_, K, flops);
     // the model is coarse: leave the habitual choice (256x256 from ~200 tiles up) only for a clear predicted win
@@ -954,6 +1004,7 @@ static void fill(GemmArgs& g, const void* A, int lda, const void* W, int ldw, co
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.gelu_from_col = (gelu_from_col + 7) & ~7;      // the GELU boundary is honoured per 8-column vector (callers pass multiples of 8)
     g.wscale = nullptr;
+    g.w8 = 0;
 }
 
 static int fill_qkv(GemmArgs& g, const rgn_qkv_epilogue* e, int N) {
@@ -991,7 +1042,7 @@ static int gemm1(const void* A, int lda, const void* W, int ldw, const float* ws
     if (rc || (rc = w8_check(W, ldw, wsc))) return rc;
     GemmGroup gg;
     fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, gate, resid, out_rows);
-    gg.p[0].wscale = wsc;
+    gg.p[0].wscale = wsc; gg.p[0].w8 = wsc != nullptr;
     gg.p[1] = gg.p[0];
     return gemm_dispatch(gg, 1, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1011,7 +1062,7 @@ static int gemm2(const void* A0, int lda0, const void* W0, const float* ws0, con
     GemmGroup gg;
     fill(gg.p[0], A0, lda0, W0, K, bias0, C0, ldc0, M0, N, K, gelu_from_col, gate0, resid0, nullptr);
     fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, gelu_from_col, gate1, resid1, nullptr);
-    gg.p[0].wscale = ws0; gg.p[1].wscale = ws1;
+    gg.p[0].wscale = ws0; gg.p[1].wscale = ws1; gg.p[0].w8 = gg.p[1].w8 = ws0 != nullptr;
     return gemm_dispatch(gg, 2, epilogue, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1024,7 +1075,7 @@ static int gemm_qkv1(const void* A, int lda, const void* W, int ldw, const float
     GemmGroup gg;
     fill(gg.p[0], A, lda, W, ldw, bias, C, ldc, M, N, K, gelu_from_col, nullptr, nullptr, nullptr);
     if ((rc = fill_qkv(gg.p[0], e, N))) return rc;
-    gg.p[0].wscale = wsc;
+    gg.p[0].wscale = wsc; gg.p[0].w8 = wsc != nullptr;
     gg.p[1] = gg.p[0];
     return gemm_dispatch(gg, 1, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -1046,7 +1097,7 @@ static int gemm_qkv2(const void* A0, int lda0, const void* W0, const float* ws0,
     fill(gg.p[1], A1, lda1, W1, K, bias1, C1, ldc1, M1, N, K, N, nullptr, nullptr, nullptr);
     if ((rc = fill_qkv(gg.p[0], e0, N))) return rc;
     if ((rc = fill_qkv(gg.p[1], e1, N))) return rc;
-    gg.p[0].wscale = ws0; gg.p[1].wscale = ws1;
+    gg.p[0].wscale = ws0; gg.p[1].wscale = ws1; gg.p[0].w8 = gg.p[1].w8 = ws0 != nullptr;
     return gemm_dispatch(gg, 2, RGN_EPI_QKV, workspace, workspace_bytes, (hipStream_t)stream);
 }
 

@@ -604,3 +604,30 @@ def test_gemm_fp8_weights_fused_qkv_epilogue_and_pair():
     ops.gemm(A, W0q, b0, s0)
     ops.gemm(A1, W1q, b0, s1)
     assert torch.equal(o0, s0) and torch.equal(o1, s1)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4608, 3072, 3072, "gate"), (8704, 21504, 3072, "gelu"), (2048, 704, 15360, "bias")])
+def test_gemm_fp8_weights_widened_once_bit_identical_to_fp8_tiles(M, N, K, epi, monkeypatch):
+    """Large-M problems on fp8 weights widen W (exact e4m3 -> bf16) once per call into the workspace tail and run the
+    hand-scheduled bf16 loop with the per-channel scale still on the fp32 accumulator: bit-identical to the kernel that
+    converts fp8 tiles in registers (RGN_W8_WIDEN_MIN_M=0)."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    A = bf(torch.randn(M, K, generator=g)).cuda()
+    Wq = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
+    b = bf(torch.randn(N, generator=g)).cuda()
+    gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
+    outs = []
+    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")          # whole-K tiles: the two paths' planners may cut remainders differently
+    for min_m in ("0", "1"):
+        monkeypatch.setenv("RGN_W8_WIDEN_MIN_M", min_m)
+        if epi == "gate":
+            o = x.clone()
+            ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
+        else:
+            o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GELU if epi == "gelu" else ops.EPI_BIAS, gelu_from_col=N // 2 // 8 * 8)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    assert torch.isfinite(outs[0].float()).all()
