@@ -173,7 +173,10 @@ int rgn_gemm_bf16_qkv_pair(const void* A0, int lda0, const void* W0, const void*
  * bf16 / fp32 exactly as in the bf16 calls; the fp8 -> bf16 conversion is exact (v_cvt_scalef32_pk_bf16_fp8 in registers, after
  * the LDS read), the scale multiplies the fp32 accumulator.  Replaces nothing in the reference (which ships bf16 weights):
  * storage format of the [EXT] Linear weights only; quantisation (per-channel absmax / 448) is done by the caller
- * (regione_amd.harness.flux.FluxTransformer2DModel.quantize_fp8_). */
+ * (regione_amd.harness.flux.FluxTransformer2DModel.quantize_fp8_).
+ * With a workspace and >= 2048 rows in total the call first widens W8 to bf16 (exact) into the TAIL of the workspace
+ * (N x K x 2 bytes per problem, >= 64 MiB left for the split remainders) and runs the bf16 K loop on it - same result bit
+ * for bit, weights stay fp8 in HBM (env RGN_W8_WIDEN_MIN_M, 0 = never). */
 int rgn_gemm_w8(const void* A, int lda, const void* W8, int ldw, const float* wscale, const void* bias, void* C, int ldc,
                 int M, int N, int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
                 const int64_t* out_rows, void* workspace, size_t workspace_bytes, void* stream);
