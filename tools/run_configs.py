@@ -164,13 +164,15 @@ CASES = {
                                  dict(cfg_scale=6.0, Tn=384, vanilla_runs=1, steps=50, fp8=True,
                                       helper_kw=dict(num_inference_steps=50, gamma="resample", warmup_step=10, post_step=4,
                                                      refresh_step="28", cache_threshold=0.02)))],
+    "qwen_sweep": [("qwen_image_edit_1024_cfg4_ke%02d" % int(f * 100), "qwen", 1024, f, dict(cfg_scale=4.0, Tn=384, vanilla_runs=1))
+                   for f in (0.05, 0.15)],
     "qwen_1024": [("qwen_image_edit_1024_cfg4 (configs[2])", "qwen", 1024, 0.25, dict(cfg_scale=4.0, Tn=384))],
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("step1x_v1p2_2048_50")])
+    ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("step1x_v1p2_2048_50") and c != "qwen_sweep"])
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     device = torch.device("cuda", 0)
