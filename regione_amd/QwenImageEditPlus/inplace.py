@@ -1,6 +1,8 @@
 """RegionE patch set for Qwen-Image-Edit-2509 ("Plus") - RegionE/QwenImageEditPlus/inplace.py.
 Same kernels and protocol as QwenImageEdit; the deltas are its own gamma table (:47-50) and multi-image
-conditioning, which is list handling in front of the denoise loop (:229-244, :296-299)."""
+conditioning (:229-244, :296-299), which lives in the shared code: `cond_shapes` (one rotary frame per condition image,
+K/V rows = text + latent + every image) in harness/qwen.py + QwenImageEdit/inplace.py, the list handling in front of the
+loop (per-image `calculate_dimensions`, VAE sizes, `encode_prompt(image=[...])`) in adapters._hosted_qwen."""
 import torch
 
 from ..QwenImageEdit import inplace as q
