@@ -43,6 +43,7 @@ struct AttnArgs {
     // round-aware launch: this launch covers items [item_offset, item_offset + nitems_launch); in
     // SPLIT mode every item is cut into nsplit KV ranges whose partial (O, m, l) go to `ws`.
     int item_offset, nitems_launch, nsplit;
+    int dephase;                 // hand-scheduled loop: 0 = every wave in role A, 1 = waves 4..7 in role B, 2 = odd waves in role B
     float* ws;
 };
 
@@ -420,6 +421,9 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
         uint32_t stg_k = __builtin_amdgcn_readfirstlane(lds0 + 32768u), stg_v = __builtin_amdgcn_readfirstlane(lds0), stg_d = stg_v;
         const uint32_t wdst = __builtin_amdgcn_readfirstlane((uint32_t)wave * 2048u);
         uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) >> 1), rem = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) & 1u);
+        // role B = tile barrier between X and Y instead of ahead of X (tools/gen_attn_loop.py:body): the two waves of a SIMD
+        // (wave w and w + 4) take different roles so that their exp-heavy phases alternate
+        const uint32_t role = __builtin_amdgcn_readfirstlane(g.dephase == 1 ? (uint32_t)(wave >> 2) & 1u : g.dephase == 2 ? (uint32_t)wave & 1u : 0u);
         const float sl2e = g.scale_log2e;
         const uint64_t sl2e2 = ((uint64_t)__float_as_uint(sl2e) << 32) | __float_as_uint(sl2e);    // both halves: packed-fp32 operand
         uint32_t stmp, stmp2, sdst;
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
                        [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]),
                        [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]),
                        [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last),
-                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e), [sl2e2] "s"(sl2e2)
+                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e), [sl2e2] "s"(sl2e2), [ones2] "s"(0x3f803f80u), [role] "s"(role)
                      : RGN_ATTN_LOOP_CLOBBERS);
     }
     // O^T accumulator: a[db * 16 + r] (zero when this split piece had no tiles - but then the launch has none either)
@@ -684,6 +688,7 @@ int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_sla
     g.ldq = ldq; g.ldo = ldo; g.skv_pad = skv_pad; g.Sq = Sq; g.Skv = Skv; g.H = H;
     g.scale_log2e = scale * 1.4426950408889634f;
     g.item_offset = 0; g.nitems_launch = 0; g.nsplit = 1; g.ws = nullptr;
+    { const char* e = getenv("RGN_ATTN_DEPHASE"); g.dephase = e ? atoi(e) : 0; }   // only meaningful for an ATTN_DEPHASE=1 build of the loop
     hipStream_t st = (hipStream_t)stream;
     // 8-wave workgroups (256 query rows share each K/V tile, 1 per CU) unless the query set is tiny
     int variant = (H * ((Sq + 255) / 256) >= 96) ? 8 : 4;

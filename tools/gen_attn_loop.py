@@ -37,7 +37,7 @@ ACC = [TMP + 8 + i for i in range(4)]           # row-sum accumulators
 T_R = [TMP + 12 + i for i in range(4)]          # rescale temporaries
 K_TILE, STAGE, NSTAGE = 16384, 32768, 5
 LDS_END = STAGE * NSTAGE
-CFG = dict(D=4, novalu=False, noread=False, prio=False, pkfma=False, pkadd=False)      # generator knobs (main() emits several variants)
+CFG = dict(D=4, novalu=False, noread=False, prio=False, pkfma=False, pkadd=False, dot2sum=False, dephase=False)      # generator knobs (main() emits several variants)
 
 
 def v(n, w=1):
@@ -149,6 +149,13 @@ def exp_ops(p):
 def rowsum_ops(p):
     """l_run += sum of the 32 P values of this lane: two packed accumulators (4 running sums), 17 instructions"""
     b = S_BASE[p]
+    if CFG["dot2sum"]:
+        # ATTN_DOT2SUM=1 (measurement build): row sum of the bf16-ROUNDED P (the values the PV product uses) with
+        # v_dot2_f32_bf16 against (1, 1): 16 + 4 instructions instead of 36
+        ops = [f"v_dot2_f32_bf16 {v(ACC[i % 4])}, {v(PF + i)}, %[ones2], " + ("0" if i < 4 else v(ACC[i % 4])) for i in range(16)]
+        ops += [f"v_add_f32 {v(ACC[0])}, {v(ACC[0])}, {v(ACC[1])}", f"v_add_f32 {v(ACC[2])}, {v(ACC[2])}, {v(ACC[3])}",
+                f"v_add_f32 {v(ACC[0])}, {v(ACC[0])}, {v(ACC[2])}", f"v_add_f32 %[l_run], %[l_run], {v(ACC[0])}"]
+        return ops
     if not CFG["pkadd"]:
         return rowsum_ops_scalar(p)
     assert ACC[0] % 2 == 0
@@ -327,15 +334,29 @@ def phase_y(st, p, full, prefetch_k):
     interleave(st, mf, fill, gaps)
 
 
-def body(st, p, full, tag):
+def body(st, p, full, tag, role="A"):
+    """One KV tile.  Role A: tile barrier + DMA issue at the HEAD of the body (before X); role B: between X and Y.  Both roles
+    execute the same phase sequence and one barrier per tile, so when all waves meet at barrier t the role-A waves are about to
+    start X(t) and the role-B waves have just finished it: behind the barrier A runs X (80 VALU instructions, 2/3 of them
+    quarter-rate exp) while B runs Y (61 cheap ones), then the other way round.  Two waves of one SIMD with different roles
+    therefore never want the VALU for their exp phases at the same time.  ATTN_DEPHASE=1 (measurement build; the kernel picks the
+    roles with RGN_ATTN_DEPHASE=1: waves 4..7 in role B, =2: odd waves): correct, and within +-0.5 % of the single-role loop on
+    every shape (MI355X) - the waves of a SIMD evidently do not stay phase-locked behind the barrier anyway - so the shipped loop
+    has one role.  Ring safety is unchanged: at barrier t every wave has
+    finished Y(t-1) (the stage tile t+4 overwrites), and role B's early X(t) reads K(t+1), which landed by barrier t-1."""
     rescale_block(st, tag)
-    if full:
+
+    def tile_barrier():
         st.emit("s_waitcnt vmcnt(4)")                      # tile t+2 has landed (t+3 may be in flight)
         st.emit("s_barrier")
         dma_issue(st)                                      # tile t+4 -> the stage of tile t-1
+    if full and role == "A":
+        tile_barrier()
     phase_x(st, p, full)
     if full:
         advance(st, "stg_k")                               # next X reads K of tile t+2
+    if full and role == "B":
+        tile_barrier()
     phase_y(st, p, full, prefetch_k=full)
     advance(st, "stg_v")
     # a trailing full body's K prefetch reads (t+2) are harmless when tile t+2 does not exist: the clamped DMA re-fetched
@@ -376,30 +397,45 @@ def prologue(st):
         k_read(st, f)
 
 
+def emit_loop(st, entry, role, L):
+    """the tile loop for one role; L = label base (numeric local labels L+1 .. L+4, rescale labels 9<tag>)"""
+    t = lambda k: str(L + k)
+    st.pending = list(entry)
+    st.emit("s_cmp_eq_u32 %[cnt], 0")
+    st.emit(f"s_cbranch_scc1 {L + 2}f")
+    st.emit(f"{L + 1}:")
+    body(st, 0, True, t(1), role)
+    body(st, 1, True, t(2), role)
+    assert set(st.pending) <= set(entry)                 # the loop head assumed at least these reads in flight: conservative
+    st.emit("s_sub_u32 %[cnt], %[cnt], 1")
+    st.emit("s_cmp_lg_u32 %[cnt], 0")
+    st.emit(f"s_cbranch_scc1 {L + 1}b")
+    st.emit(f"{L + 2}:")
+    st.emit("s_cmp_eq_u32 %[rem], 0")
+    st.emit(f"s_cbranch_scc1 {L + 3}f")
+    body(st, 0, True, t(3), role)
+    body(st, 1, False, t(4), role)
+    st.emit(f"s_branch {L + 4}f")
+    st.emit(f"{L + 3}:")
+    st.pending = list(entry)
+    body(st, 0, False, t(5), role)
+    st.emit(f"{L + 4}:")
+
+
 def emit():
     st = Stream()
     prologue(st)
     entry = [] if CFG["noread"] else [("K", f) for f in range(CFG["D"])]      # LDS reads in flight at every body entry
     assert st.pending == entry
-    st.emit("s_cmp_eq_u32 %[cnt], 0")
-    st.emit("s_cbranch_scc1 2f")
-    st.emit("1:")
-    body(st, 0, True, "1")
-    body(st, 1, True, "2")
-    assert set(st.pending) <= set(entry)                 # the loop head assumed at least these reads in flight: conservative
-    st.emit("s_sub_u32 %[cnt], %[cnt], 1")
-    st.emit("s_cmp_lg_u32 %[cnt], 0")
-    st.emit("s_cbranch_scc1 1b")
-    st.emit("2:")
-    st.emit("s_cmp_eq_u32 %[rem], 0")
-    st.emit("s_cbranch_scc1 3f")
-    body(st, 0, True, "3")
-    body(st, 1, False, "4")
-    st.emit("s_branch 4f")
-    st.emit("3:")
-    st.pending = list(entry)
-    body(st, 0, False, "5")
-    st.emit("4:")
+    if CFG["dephase"]:
+        st.emit("s_cmp_lg_u32 %[role], 0")
+        st.emit("s_cbranch_scc1 50f")
+    emit_loop(st, entry, "A", 10)
+    if CFG["dephase"]:
+        st.emit("s_branch 60f")
+        st.emit("50:")
+        emit_loop(st, entry, "B", 20)
+        st.emit("60:")
     st.emit("s_waitcnt vmcnt(0)")
     st.emit("s_waitcnt lgkmcnt(0)")
     st.emit("s_barrier")
@@ -420,7 +456,8 @@ def main():
         f.write("// GENERATED by tools/gen_attn_loop.py - do not edit.  Hand-scheduled KV loop of attention_asm_kernel.\n")
         for name, kw in variants:
             CFG.update(dict(D=4, novalu=False, noread=False, prio=False, pkfma=os.environ.get("ATTN_PKFMA", "0") == "1",
-                            pkadd=os.environ.get("ATTN_PKADD", "0") == "1"))
+                            pkadd=os.environ.get("ATTN_PKADD", "0") == "1", dot2sum=os.environ.get("ATTN_DOT2SUM", "0") == "1",
+                            dephase=os.environ.get("ATTN_DEPHASE", "0") == "1"))
             CFG.update(kw)
             lines = emit()
             n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
