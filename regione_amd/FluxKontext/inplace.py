@@ -25,6 +25,7 @@ from typing import Optional
 import torch
 
 from .. import ops
+from .. import dist as D
 from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..harness import flux as H
 from .utils import FluxKontextManager, ids_gather
@@ -141,21 +142,25 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                 if MANAGER.is_full_input_step():                                # inplace.py:331-332
                     latent_model_input = torch.cat([latents, image_latents], dim=1)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
-                self.transformer.out_rows_hint = latents.size(1)
-                noise_pred = self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000,
-                                              guidance=guidance, pooled_projections=pooled_prompt_embeds,
-                                              encoder_hidden_states=prompt_embeds, txt_ids=text_ids,
-                                              img_ids=latent_ids, joint_attention_kwargs={"tag": "cond"},
-                                              return_dict=False)[0]
-                noise_pred = noise_pred[:, : latents.size(1)]
-                if do_true_cfg:                                                 # inplace.py:349-364
+
+                def branch(embeds, pooled_e, tag):
                     self.transformer.out_rows_hint = latents.size(1)
-                    neg = self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000,
-                                           guidance=guidance, pooled_projections=negative_pooled_prompt_embeds,
-                                           encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,
-                                           img_ids=latent_ids, joint_attention_kwargs={"tag": "uncond"},
-                                           return_dict=False)[0][:, : latents.size(1)]
+                    return self.transformer(hidden_states=latent_model_input, timestep=timestep / 1000, guidance=guidance,
+                                            pooled_projections=pooled_e, encoder_hidden_states=embeds, txt_ids=text_ids,
+                                            img_ids=latent_ids, joint_attention_kwargs={"tag": tag},
+                                            return_dict=False)[0][:, : latents.size(1)]
+                if do_true_cfg:                                                 # inplace.py:349-364
+                    # two forwards per computed step: side by side on two streams in region steps, unless the reference's
+                    # shared K/V cache (strict_reference, quirk A-4) makes the second forward depend on the first
+                    full_step = MANAGER.is_full_input_step()
+                    conc = (not getattr(MANAGER, "strict_reference", False)) and D.branches_concurrent(
+                        MANAGER, (full_step, prompt_embeds.shape[1], negative_prompt_embeds.shape[1]), not full_step)
+                    noise_pred, neg = D.run_cfg_branches(None, lambda: branch(prompt_embeds, pooled_prompt_embeds, "cond"),
+                                                         lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, "uncond"),
+                                                         concurrent=conc)
                     noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
+                else:
+                    noise_pred = branch(prompt_embeds, pooled_prompt_embeds, "cond")
                 cache = noise_pred                                              # inplace.py:365
             if trace is not None:
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))

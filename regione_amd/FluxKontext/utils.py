@@ -178,6 +178,7 @@ class FluxKontextManager:
         self.image_rotary_emb = None
         self.rope_full_by_T = {}         # text length -> (cos, sin) of [text ids ; FULL latent ids]
         self._sel_by_T, self._ropeq_by_T = {}, {}
+        self._branch_warm = set()         # regione_amd.dist.branches_concurrent: step kinds whose tables exist
         self.latent_ids = latent_ids
         self.refresh_step_real_time = list(self.refresh_step)
 

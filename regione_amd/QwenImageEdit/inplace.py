@@ -111,9 +111,12 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
                     return tr(hidden_states=x, timestep=timestep / 1000, encoder_hidden_states=embeds, img_shapes=img_shapes,
                               latent_ids=latent_ids, attention_kwargs={"tag": tag}, return_dict=False)[0][:, : latents.size(1)]
                 if do_true_cfg:                                                          # :371-405
+                    full_step = MANAGER.is_full_input_step()
+                    conc = D.branches_concurrent(MANAGER, (full_step, prompt_embeds.shape[1], negative_prompt_embeds.shape[1]),
+                                                 not full_step)
                     noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                                          lambda: branch(prompt_embeds, "cond"),
-                                                         lambda: branch(negative_prompt_embeds, "uncond"))
+                                                         lambda: branch(negative_prompt_embeds, "uncond"), concurrent=conc)
                     noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
                 else:
                     noise_pred = branch(prompt_embeds, "cond")

@@ -104,9 +104,12 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
                     return tr(hidden_states=x, timestep=timestep / 1000, guidance=None, encoder_hidden_states=embeds,
                               prompt_embeds_mask=None, txt_ids=ids, img_ids=latent_ids, joint_attention_kwargs={"tag": tag},
                               return_dict=False)[0][:, : latents.size(1)]
+                full_step = MANAGER.is_full_input_step()
+                conc = D.branches_concurrent(MANAGER, (full_step, prompt_embeds.shape[1], negative_prompt_embeds.shape[1]),
+                                             not full_step)
                 pos, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                               lambda: branch(prompt_embeds, text_ids, "cond"),
-                                              lambda: branch(negative_prompt_embeds, neg_text_ids, "uncond"))
+                                              lambda: branch(negative_prompt_embeds, neg_text_ids, "uncond"), concurrent=conc)
                 mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN                    # :421
                 noise_pred = TO.R.cfg_combine(pos, neg, true_cfg_scale, mode, process_norm_power)
                 cache = noise_pred

@@ -142,10 +142,54 @@ def make_cfg_pair(dist) -> CfgBranchPair:
     return CfgBranchPair(dist, mine, rank % 2)
 
 
-def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch.Tensor], run_uncond: Callable[[], torch.Tensor]):
-    """Both CFG forwards of one computed step: sequentially (reference order: cond, then uncond) without a pair,
-    one branch per rank + exchange with one."""
-    if pair is None:
+_side_streams = {}
+
+
+def _branch_streams_mode() -> int:
+    """RGN_BRANCH_STREAMS: 0 = the two forwards of a step run one after the other on the caller's stream (reference order),
+    1 (default) = the uncond forward of a step that can profit runs on a side stream, 2 = of every computed step."""
+    import os
+    return int(os.environ.get("RGN_BRANCH_STREAMS", "1"))
+
+
+def branches_concurrent(owner, key, region_step: bool) -> bool:
+    """May the two forwards of this computed step run on two streams?  Not the first time a (step kind, text lengths) key is
+    seen by `owner` (the manager of the edit / the vanilla pipeline call): that forward pair builds the lazily cached tables
+    (rotary rows of the edited ids, K/V slabs) the later ones share, and runs in order.  Owners clear `_branch_warm` whenever
+    they drop those tables."""
+    mode = _branch_streams_mode()
+    if mode <= 0 or (mode == 1 and not region_step):
+        return False
+    warm = owner.__dict__.setdefault("_branch_warm", set())
+    if key in warm:
+        return True
+    warm.add(key)
+    return False
+
+
+def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch.Tensor], run_uncond: Callable[[], torch.Tensor],
+                     concurrent: bool = False):
+    """Both CFG forwards of one computed step: without a pair sequentially in the reference's order (cond, then uncond) - or,
+    with `concurrent` (the caller says the two forwards touch disjoint state: per-branch K/V caches, tables already built),
+    the uncond forward on a SIDE STREAM forked from the caller's stream and joined before the combine: the same launches
+    with the same arguments, so the results are bit-identical, but a region step's launches (72 ... 288 workgroups on 256
+    CUs, a drain and a fill at every kernel boundary) interleave with the other branch's instead of leaving CUs idle.
+    The engine keeps one activation workspace and one split-K / KV-split scratch per stream.  With a pair: one branch per
+    rank + exchange."""
+    if pair is not None:
+        return pair.exchange(run_cond() if pair.role == "cond" else run_uncond())
+    if not (concurrent and torch.cuda.is_available()):
         pos = run_cond()
         return pos, run_uncond()
-    return pair.exchange(run_cond() if pair.role == "cond" else run_uncond())
+    main = torch.cuda.current_stream()
+    key = (main.device_index, main.cuda_stream)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=main.device)
+    side.wait_stream(main)                       # fork: everything enqueued so far (latents, caches of earlier steps) is visible
+    pos = run_cond()                             # host order stays cond -> uncond; the GPU runs them side by side
+    with torch.cuda.stream(side):
+        neg = run_uncond()
+    main.wait_stream(side)                       # join before the combine
+    neg.record_stream(main)
+    return pos, neg

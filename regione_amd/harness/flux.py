@@ -629,6 +629,17 @@ class FluxTransformer2DModel:
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
+    def _ws_for_stream(self) -> "Workspace":
+        """Activation buffers of the forward being enqueued: `self.ws` on the stream the engine was built on, one more set per
+        other stream (the uncond forward of a CFG step may run on a side stream, regione_amd.dist.run_cfg_branches)."""
+        sid = torch.cuda.current_stream(self.device).cuda_stream
+        lanes = self.__dict__.setdefault("_ws_lanes", {})
+        if not lanes:
+            lanes[sid] = self.ws
+        if sid not in lanes:
+            lanes[sid] = Workspace(self.cfg_model, self.device)
+        return lanes[sid]
+
     def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict,
              joint_attention_kwargs=None, out_rows=None):
         """Shared body of the vanilla and the RegionE forward (inplace.py:469-576).  `out_rows` (or the one-shot attribute
@@ -642,7 +653,7 @@ class FluxTransformer2DModel:
         M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
         Mo = M if out_rows is None else min(int(out_rows), M)
         R = T + M
-        ws = self.ws
+        ws = self._ws_for_stream()
         ws.ensure(R, R)
         d = self.cfg_model.d
         ops.gemm(hidden_states[0], self.x_embedder_weight, self.x_embedder_bias, ws.x[T:R])

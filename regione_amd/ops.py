@@ -153,8 +153,9 @@ _gemm_ws = {}
 
 
 def gemm_workspace(device) -> torch.Tensor:
-    """fp32 scratch for the round-aware GEMM schedule (allocated once per device)."""
-    key = str(device)
+    """fp32 scratch for the round-aware GEMM schedule (allocated once per device and stream: two forwards running on
+    two streams must not share split-K partials)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _gemm_ws:
         _gemm_ws[key] = torch.empty(_lib.lib().rgn_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device)
     return _gemm_ws[key]
@@ -339,8 +340,8 @@ _attn_ws = {}
 
 
 def attention_workspace(device) -> torch.Tensor:
-    """fp32 scratch for the round-aware attention schedule (allocated once per device)."""
-    key = str(device)
+    """fp32 scratch for the round-aware attention schedule (allocated once per device and stream)."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     if key not in _attn_ws:
         n = _lib.lib().rgn_attention_workspace_bytes(0, 0)
         _attn_ws[key] = torch.empty(n // 4, dtype=torch.float32, device=device)

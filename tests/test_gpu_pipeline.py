@@ -640,3 +640,53 @@ def test_gpu_eager_scalars_switch_rounds_the_decay_ratio_like_torch_device_kerne
         assert checked == kinds.count("C") > 0
         helper.disable()
     assert differ > 0                                                               # the two conventions really do differ
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_cfg_branches_on_two_streams_bit_identical_to_sequential(golden, mode, monkeypatch):
+    """The uncond forward of a two-forward CFG step may run on a side stream next to the cond forward (region steps by
+    default, RGN_BRANCH_STREAMS=2: every computed step): same launches, same arguments, one activation workspace and one
+    split-K / KV-split scratch per stream -> the whole 28-step edit is bit-identical to the sequential run (mode 0), trace
+    included, for the tagged-CFG families and for FLUX true CFG."""
+    from regione_amd.harness import qwen as HQ
+    cfg = synth.FluxConfig(**synth.QWEN_TOY)
+    h = w = 16
+    wts = synth.make_flux_weights(cfg, seed=6, dtype=torch.bfloat16, w_std=0.05)
+    lat, _, prompt, _ = synth.make_edit_inputs(h, w, 32, cfg, seed=9, dtype=torch.bfloat16)
+    _, _, nprompt, _ = synth.make_edit_inputs(h, w, 24, cfg, seed=10, dtype=torch.bfloat16)
+    img = golden("qwen_toy_bf16")["image_latents"]
+    pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    kw = dict(image=img.cuda(), prompt_embeds=prompt.cuda(), negative_prompt_embeds=nprompt.cuda(), height=h * 16, width=w * 16,
+              latents=lat.cuda(), true_cfg_scale=4.0, return_dict=False)
+    runs = {}
+    for m in ("0", mode, "0", mode):
+        monkeypatch.setenv("RGN_BRANCH_STREAMS", m)
+        trace = {}
+        out = pipe(trace=trace, **kw)[0]
+        torch.cuda.synchronize()
+        runs.setdefault(m, []).append((out.clone(), [x.clone() for x in trace["noise_pred"]], "".join(trace["kind"])))
+    a, b = runs["0"][0], runs[mode][0]
+    assert a[2] == b[2] and "R" in a[2]
+    assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    assert torch.equal(runs[mode][0][0], runs[mode][1][0]) and torch.equal(runs["0"][0][0], runs["0"][1][0])
+    # FLUX true CFG (per-branch caches): same property
+    fcfg = synth.FluxConfig(**synth.TOY)
+    fw = synth.make_flux_weights(fcfg, seed=42, dtype=torch.bfloat16, w_std=0.05)
+    flat, fimg, fp, fpool = synth.make_edit_inputs(16, 16, 24, fcfg, seed=5, dtype=torch.bfloat16)
+    _, _, fn, fnpool = synth.make_edit_inputs(16, 16, 24, fcfg, seed=6, dtype=torch.bfloat16)
+    fpipe = _toy_pipe(fw, fcfg)
+    fh = RegionEHelper(fpipe)
+    fh.set_params(threshold=0.1)
+    fh.enable()
+    fkw = dict(image=fimg.cuda(), prompt_embeds=fp.cuda(), pooled_prompt_embeds=fpool.cuda(), negative_prompt_embeds=fn.cuda(),
+               negative_pooled_prompt_embeds=fnpool.cuda(), true_cfg_scale=6.0, height=256, width=256, latents=flat.cuda(),
+               guidance_scale=2.5, return_dict=False)
+    outs = []
+    for m in ("0", mode):
+        monkeypatch.setenv("RGN_BRANCH_STREAMS", m)
+        outs.append(fpipe(**fkw)[0].clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])

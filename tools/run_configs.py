@@ -166,13 +166,15 @@ CASES = {
                                                      refresh_step="28", cache_threshold=0.02)))],
     "qwen_sweep": [("qwen_image_edit_1024_cfg4_ke%02d" % int(f * 100), "qwen", 1024, f, dict(cfg_scale=4.0, Tn=384, vanilla_runs=1))
                    for f in (0.05, 0.15)],
+    "qwen_quick": [("qwen_image_edit_1024_cfg4 (configs[2]), one full-token run", "qwen", 1024, 0.25, dict(cfg_scale=4.0, Tn=384, vanilla_runs=1))],
+    "flux_cfg_quick": [("flux_1024_truecfg6_ke25, one full-token run", "flux", 1024, 0.25, dict(cfg_scale=6.0, vanilla_runs=1))],
     "qwen_1024": [("qwen_image_edit_1024_cfg4 (configs[2])", "qwen", 1024, 0.25, dict(cfg_scale=4.0, Tn=384))],
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("step1x_v1p2_2048_50") and c != "qwen_sweep"])
+    ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("step1x_v1p2_2048_50") and c not in ("qwen_sweep", "qwen_quick", "flux_cfg_quick")])
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     device = torch.device("cuda", 0)
