@@ -125,3 +125,28 @@ def test_bench_two_ranks_share_the_gpu(extra):
     assert all(p["edit_s"] > 0 for p in d["per_rank"]) and d["per_rank"][0]["K_e"] < d["per_rank"][1]["K_e"]
     assert ("true CFG 6.0" in d["config"]["workload"]) == bool(extra)
     assert abs(d["value"] - 28 * 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+def test_bench_json_contract_single_gpu():
+    """`python bench.py` prints exactly one JSON line with the fields the driver and SURVEY.md section 8(d) ask for (toy trunk
+    so that the CPU-baseline leg takes seconds; the field set does not depend on the size)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "1", "--warmup", "1", "--toy"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "steps/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "steps/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    assert abs(d["value"] - 28 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
