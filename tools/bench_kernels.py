@@ -74,6 +74,11 @@ def bench_small():
     pairs = [("R qkv", 1024, 512, 9216, 3072), ("R out", 1024, 512, 3072, 3072), ("R ff1", 1024, 512, 12288, 3072),
              ("R ff2", 1024, 512, 3072, 12288), ("R5% ff2", 196, 512, 3072, 12288), ("R5% ff1", 196, 512, 12288, 3072),
              ("Qwen R ff2 T384", 1024, 384, 3072, 12288)]
+    if os.environ.get("GEMM_BATCHED_BRANCHES"):      # what batching the cond + uncond branches of a Qwen region step would buy
+        pairs = [(f"Q {n} cond", 1024, 512, N, K) for n, N, K in (("qkv", 9216, 3072), ("out", 3072, 3072), ("ff1", 12288, 3072), ("ff2", 3072, 12288))]
+        pairs += [(f"Q {n} uncond", 1024, 384, N, K) for n, N, K in (("qkv", 9216, 3072), ("out", 3072, 3072), ("ff1", 12288, 3072), ("ff2", 3072, 12288))]
+        pairs += [(f"Q {n} both", 2048, 896, N, K) for n, N, K in (("qkv", 9216, 3072), ("out", 3072, 3072), ("ff1", 12288, 3072), ("ff2", 3072, 12288))]
+        singles = []
     gated = os.environ.get("GEMM_EPI") == "gate"          # gated-residual epilogue (out-projections, ff2, proj_out) instead of bias
     cold = os.environ.get("GEMM_COLD")                    # rotate over enough weight copies to overflow the Infinity Cache
     only = os.environ.get("GEMM_ONLY")
