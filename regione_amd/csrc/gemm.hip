@@ -784,15 +784,15 @@ static inline int tiles(int M, int N, int b) { return ((M + b - 1) / b) * ((N + 
 // ------------------------------------------------------------------------------------------------
 struct GemmPlan { int nsplit; float cost_us; bool asm_pieces; };
 
-static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes, bool asm4w) {
+static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes, bool asm4w, double wbytes) {
     const int slots = 256, nk = K / BK;
     const size_t tile_bytes = (size_t)256 * 256 * 4;
     const int full_rounds = nt / slots, left = nt - full_rounds * slots;
     // microseconds per K step of 64 and per tile (prologue + epilogue), tools/bench_kernels.py K sweeps:
     //   8-wave compiler-scheduled: 1.5 + 10 (FULL), 1.45 + 5 (PARTIAL: fp32 fragment dump instead of the epilogue), two extra
     //   launches (partial, reduce) ~10 and ~0.07 per partial tile of L2 / MALL traffic;
-    //   4-wave hand-scheduled: 1.25 + 9 (FULL), 1.25 + 6 per piece (PARTIAL); its reduce launch reads nsplit x 256 KiB per tile
-    //   (~2 per partial) and runs the epilogue (~8 with the launch gap).
+    //   4-wave hand-scheduled: 1.25 + 9 (FULL), 1.25 + 8 per piece (PARTIAL); the reduce launch reads 256 KiB per piece
+    //   (~0.11 per piece, measured from 216 to 720 pieces) and runs the epilogue (~6 with the launch gap).
     const float ks = asm4w ? 1.25f : 1.5f, tile_us = asm4w ? 9.0f : 10.0f;
     const float full_cost = (float)full_rounds * ((float)nk * ks + tile_us);
     GemmPlan p{1, full_cost + (left > 0 ? (float)nk * ks + tile_us : 0.0f), false};
@@ -809,7 +809,10 @@ static GemmPlan plan256(int nt, int K, bool can_split, size_t ws_bytes, bool asm
         // fixup_ab.sh: R proj_out 162 -> 137 us, R ff2 137 -> 115), else on the 8-wave one; the reduce pass is the 8-wave one
         float cost;
         const bool asm_pieces = asm4w && asm_split_on;
-        if (asm_pieces) cost = full_cost + (float)rounds * (per * 1.25f + 8.0f) + 2.0f * (float)S + 10.0f;
+        // small-M long-K problems are bound by the cold weight stream plus the partial dump, not by the K loop: ~3.5 TB/s
+        // effective (R 5 % ff2 pair: 151 MB of W, S = 6 -> 93 us measured where the loop alone would take 48)
+        const float hbm_us = (float)((wbytes + (double)blocks * 262144.0) / 3.5e6);
+        if (asm_pieces) cost = full_cost + fmaxf((float)rounds * (per * 1.25f + 8.0f), full_rounds == 0 ? hbm_us : 0.0f) + 0.11f * (float)blocks + 6.0f;
         else if (S <= 6 && nk / S >= 8) cost = full_cost + (float)rounds * (per * 1.45f + 5.0f) + 0.07f * (float)blocks + 10.0f;
         else continue;
         if (cost < p.cost_us) { p.cost_us = cost; p.nsplit = S; p.asm_pieces = asm_pieces; any_asm = asm_pieces; }
@@ -845,7 +848,8 @@ static int split128(int nt, int K, bool can_split, size_t ws_bytes) {
 
 static float estimate128(int nt, int K, double flops) {
     const int nk = K / BK, rounds = (nt + 255) / 256;
-    const float t = (float)rounds * ((float)nk * (nt <= 256 ? 0.33f : 0.36f) + 8.0f);
+    // re-fitted in round 2 on COLD weights (every layer's W comes from HBM in the pipeline): R out pair 63 us, 144-tile long-K 255 us
+    const float t = (float)rounds * ((float)nk * 0.40f + 12.0f);
     return fmaxf(t, (float)(flops / 1.05e15 * 1e6));
 }
 
@@ -972,10 +976,12 @@ static int gemm_dispatch(GemmGroup& gg, int nprob, int epilogue, void* ws, size_
     static const int asm_default = [] { const char* e = getenv("RGN_GEMM_ASM"); return e ? atoi(e) : 1; }();   // RGN_GEMM_ASM=0: A/B switch
     if (!(asm_default || (v && v[0] == '3')) || (v && v[0] == '2')) asm4w = false;
     if (gg.p[0].w8) asm4w = false;
-    const GemmPlan p256 = plan256(big, K, ws != nullptr, ws_bytes, asm4w);
+    double wbytes = 0.0;
+    for (int i = 0; i < nprob; ++i) wbytes += (double)gg.p[i].N * gg.p[i].K * 2.0;
+    const GemmPlan p256 = plan256(big, K, ws != nullptr, ws_bytes, asm4w, wbytes);
     const float e128 = estimate128(small_, K, flops);
     // the model is coarse: leave the habitual choice (256x256 from ~200 tiles up) only for a clear predicted win
-    bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < 0.92f * e128);
+    bool use_big = (big >= 200) ? !(e128 < 0.90f * p256.cost_us) : (p256.cost_us < e128);
     if (v && v[0] == '1') use_big = false;
     if (v && (v[0] == '2' || v[0] == '3')) use_big = true;
     const int b = use_big ? 256 : 128;
