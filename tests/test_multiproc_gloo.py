@@ -80,3 +80,27 @@ def test_shard_images_partition():
             parts = [D.shard_images(n, w, r) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_branch_stream_policy_first_pair_of_a_step_kind_runs_in_order(monkeypatch):
+    """regione_amd.dist.branches_concurrent: the two forwards of a CFG step may share the GPU on two streams only after a
+    forward pair of the same (step kind, text lengths) has run in order since the owner dropped its lazily built tables."""
+    from regione_amd import dist as D
+
+    class Owner:
+        pass
+    o = Owner()
+    monkeypatch.setenv("RGN_BRANCH_STREAMS", "1")
+    assert D.branches_concurrent(o, (False, 512, 384), True) is False          # first region step: builds the tables
+    assert D.branches_concurrent(o, (False, 512, 384), True) is True
+    assert D.branches_concurrent(o, (True, 512, 384), False) is False           # full steps stay sequential in mode 1
+    o._branch_warm = set()                                                      # what a manager's refresh() does
+    assert D.branches_concurrent(o, (False, 512, 384), True) is False
+    monkeypatch.setenv("RGN_BRANCH_STREAMS", "2")
+    assert D.branches_concurrent(o, (True, 512, 384), False) is False and D.branches_concurrent(o, (True, 512, 384), False) is True
+    monkeypatch.setenv("RGN_BRANCH_STREAMS", "0")
+    assert D.branches_concurrent(o, (False, 512, 384), True) is False
+    # without a GPU (or without `concurrent`) the helper keeps the reference order
+    order = []
+    a, b = D.run_cfg_branches(None, lambda: order.append("cond") or 1, lambda: order.append("uncond") or 2, concurrent=False)
+    assert (a, b) == (1, 2) and order == ["cond", "uncond"]
