@@ -120,7 +120,11 @@ int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bi
                   void* stream);
 /* `workspace` (optional, fp32 scratch, rgn_gemm_workspace_bytes()) enables the round-aware schedule:
  * output tiles that do not fill a whole round of the chip's workgroup slots are cut along K, spread
- * over all CUs and finished by a reduce pass.  NULL = plain single launch. */
+ * over all CUs and finished by a reduce pass.  NULL = plain single launch.
+ * Sizing: rgn_gemm_workspace_bytes() is a shape-independent upper bound (256 MiB = 255 remainder tiles x 4 pieces x 256 KiB of
+ * fp32 fragments, plus room for the fp8 weight widening of rgn_gemm_w8*); any smaller buffer is valid too - the planner only
+ * considers piece counts whose partials fit in `workspace_bytes` (and skips the split / the widening when nothing fits).
+ * A workspace belongs to ONE stream at a time: calls on two streams need two buffers. */
 size_t rgn_gemm_workspace_bytes(void);
 
 /* Two independent problems with the same N, K and epilogue in ONE launch (the text and image
@@ -246,8 +250,9 @@ int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_sla
                   int ldo, int Sq, int Skv, int H, float scale, void* workspace, size_t workspace_bytes,
                   void* stream);
 /* Optional fp32 scratch for the round-aware schedule: (head, q-block) items that do not fill a whole
- * round of the chip's workgroup slots are cut along KV and merged by a combine kernel.  NULL disables
- * the split (results are identical up to fp32 summation order). */
+ * round of the chip's workgroup slots are cut along KV (equal pieces or stream-K runs, chosen per launch) and merged by a
+ * combine kernel.  NULL disables the split (results are identical up to fp32 summation order).  The returned size (128 MiB)
+ * is a shape-independent upper bound; a smaller buffer limits the piece count.  One workspace per stream. */
 size_t rgn_attention_workspace_bytes(int Sq, int H);
 
 /* Device properties the host side needs for roofline reporting (no torch types). */
