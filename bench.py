@@ -202,8 +202,10 @@ def install_region_injection(pipe, h_tok, w_tok, box, image_latents, seed):
     g = torch.Generator().manual_seed(seed + 1)
     tgt = tgt + 0.1 * torch.randn(tgt.shape, generator=g)
     r0, r1, c0, c1 = box
-    tgt = tgt.to(image_latents.device)
+    pipe._bench_target = tgt.to(image_latents.device)      # a later call only swaps the target (the K_e = 5 % leg)
     sch = pipe.scheduler
+    if getattr(sch, "_bench_injection", False):
+        return
     orig = sch.step
     M = pipe._regione_manager
 
@@ -211,9 +213,10 @@ def install_region_injection(pipe, h_tok, w_tok, box, image_latents, seed):
         if M.current_step == M.warmup_step - 1:
             i = sch._step_index if sch._step_index is not None else M.current_step
             dt_final = float(sch.sigmas[-1] - sch.sigmas[i])
-            model_output = ((tgt[None] - sample.float()) / dt_final).to(model_output.dtype)
+            model_output = ((pipe._bench_target[None] - sample.float()) / dt_final).to(model_output.dtype)
         return orig(model_output, timestep, sample, **kw)
     sch.step = step
+    sch._bench_injection = True
 
 
 def cpu_baseline(cfg, T, N, K_e, plan):
@@ -238,26 +241,34 @@ def cpu_baseline(cfg, T, N, K_e, plan):
     st.refresh(None, None, T, h_tok, L // h_tok)
     temb = torch.randn(1, d, generator=g)
     caches = [O.KVCache(), O.KVCache()]
-    times = {}
+    times, samples = {}, {}
+    REPS = 3                                   # median of 3 per block (a single sample moved 9 % box to box)
+
+    def med(name, fn):
+        ts = []
+        for _ in range(REPS):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        samples[name] = [round(t, 4) for t in ts]
+        times[name] = sorted(ts)[REPS // 2]
+        return r
     with torch.no_grad():
         # FULL + store
         st.current_step = st.warmup_step - 1
         h, c = torch.randn(1, N, d, generator=g), torch.randn(1, T, d, generator=g)
-        t0 = time.perf_counter()
-        c2, h2 = O.double_block(w, "transformer_blocks.0", cfg.heads, st, caches[0], h, c, temb, rope_full, rope_full)
-        times["double_full"] = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h2, c2, temb, rope_full, rope_full)
-        times["single_full"] = time.perf_counter() - t0
+        c2, h2 = med("double_full", lambda: O.double_block(w, "transformer_blocks.0", cfg.heads, st, caches[0], h, c, temb,
+                                                           rope_full, rope_full))
+        med("single_full", lambda: O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h2, c2, temb,
+                                                  rope_full, rope_full))
         # REGION (update phase)
         st.current_step = st.warmup_step
         st.edited_ids = torch.arange(K_e).unsqueeze(0)
         sel = torch.cat([torch.arange(T), T + st.edited_ids[0]])
         rope_q = (rope_full[0][sel], rope_full[1][sel])
-        h, c = torch.randn(1, K_e, d, generator=g), torch.randn(1, T, d, generator=g)
-        t0 = time.perf_counter()
-        O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], h, c, temb, rope_q, rope_full)
-        times["single_region"] = time.perf_counter() - t0
+        hr, cr = torch.randn(1, K_e, d, generator=g), torch.randn(1, T, d, generator=g)
+        med("single_region", lambda: O.single_block(w, "single_transformer_blocks.0", cfg.heads, st, caches[1], hr, cr, temb,
+                                                    rope_q, rope_full))
         # the double block at REGION length is not timed (keeps the sample near 30 s): scaled from the single
         # block by the FULL-length ratio of the two block types
         times["double_region"] = times["single_region"] * times["double_full"] / times["single_full"]
@@ -275,11 +286,11 @@ def cpu_baseline(cfg, T, N, K_e, plan):
         pass
     return dict(value=N_STEPS / edit_s, unit="steps/s", cores=phys, logical_cpus=logical, kind="port",
                 sample=(f"oracle (torch-CPU eager fp32, {phys} threads = physical cores, {cpu_model}): 1 double + 1 single block at "
-                        f"FULL ({T}+{N} rows) timed once, 1 single block at REGION ({T}+{K_e} query rows) timed once (double-block REGION "
-                        f"time scaled by the FULL ratio) = {times['double_full'] + times['single_full'] + times['single_region']:.1f} s of CPU "
+                        f"FULL ({T}+{N} rows), 1 single block at REGION ({T}+{K_e} query rows), each timed {REPS}x (median used; double-block "
+                        f"REGION time scaled by the FULL ratio) = {sum(sum(v) for v in samples.values()):.1f} s of CPU "
                         f"work, extrapolated x{cfg.n_double}/{cfg.n_single} layers x plan {n_full}F/{n_reg}R/"
                         f"{plan.count('C')}C -> {edit_s:.0f} s per edit"),
-                block_seconds=times)
+                block_seconds=times, block_samples_s=samples)
 
 
 def main():
@@ -301,6 +312,9 @@ def main():
     ap.add_argument("--no-vanilla", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="debugging: 'gloo' lets several ranks share ONE GPU (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="debugging: every rank uses cuda:0 (single-GPU box smoke of the multi-rank path)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise the process group and run barrier / all_gather / MAX-reduce even with ONE rank (launch under "
+                         "torch.distributed.run --nproc-per-node 1): RCCL executes on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -315,7 +329,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from regione_amd import dist as D
-    dist = D.init(args.dist_backend, device) if world > 1 else None
+    force = args.force_collectives
+    dist = D.init(args.dist_backend, device) if (world > 1 or force) else None
 
     from regione_amd import RegionEHelper, synth, ops
     from oracle import regione_oracle as O            # checker / cpu_baseline leg only
@@ -353,15 +368,33 @@ def main():
     helper.enable()
     install_region_injection(pipe, h_tok, w_tok, box, img[0:1], seed=7)
 
-    def edit(trace=None):
+    def edit(trace=None, **kw):
         return pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=args.size, width=args.size,
-                    latents=lat, guidance_scale=2.5, return_dict=False, trace=trace, **cfg_kw)[0]
+                    latents=lat, guidance_scale=2.5, return_dict=False, trace=trace, **cfg_kw, **kw)[0]
+
+    def step_times(trace):
+        """GPU time of every denoising step of one (untimed) edit: an event at each `callback_on_step_end`."""
+        evs = [torch.cuda.Event(enable_timing=True)]
+        evs[0].record()
+
+        def cb(p, i, t, kw):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+            return {}
+        o = edit(trace, callback_on_step_end=cb)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:])]
+        by = {}
+        for k, m in zip(trace["kind"], ms):
+            by.setdefault(k, []).append(m)
+        return o, {k: dict(n=len(v), avg_ms=sum(v) / len(v), min_ms=min(v), max_ms=max(v)) for k, v in by.items()}
 
     rank_edit_s = []
 
     for _ in range(args.warmup):
         out = edit()
-        D.gather_latents([out], [rank], world, dist)           # warm the collective too (communicator / channel setup)
+        D.gather_latents([out], [rank], world, dist, force=force)   # warm the collective too (communicator / channel setup)
     timer = KernelTimer()
 
     def job():
@@ -382,13 +415,14 @@ def main():
             if instrument:
                 timer.unwrap()
             # every rank ends with every image's final latents (512 KB each): the only data collective
-            D.gather_latents([o], [rank], world, dist)
-    elapsed = D.timed(job, torch.cuda.synchronize, dist)       # barrier + sync both sides, MAX over ranks
+            got = D.gather_latents([o], [rank], world, dist, force=force)
+            if force:
+                assert len(got) == world and all(g is not None and g.shape == o.shape for g in got)
+    elapsed = D.timed(job, torch.cuda.synchronize, dist, force=force)       # barrier + sync both sides, MAX over ranks
 
     # characterise the run (untimed): step kinds, K_e
     trace = {}
-    out = edit(trace)
-    torch.cuda.synchronize()
+    out, step_ms = step_times(trace)
     kinds = "".join(trace["kind"])
     K_e = int(pipe._regione_manager.edited_ids.shape[1])
     f_full, f_reg = algorithmic_flops(cfg, T, N, K_e)
@@ -421,9 +455,13 @@ def main():
         "algorithmic_tflop_per_edit": flops_edit / 1e12,
         "loop_mfma_frac": flops_edit / edit_s / 1e12 / PEAK_BF16_TFLOPS,
         "model_build_s": t_build,
+        # F = full-token step (incl. the partition at step warmup-1), R = region step (T + K_e query rows), C = cache-served
+        "step_ms_by_kind": step_ms,
     }
     if per_rank is not None:
         result["per_rank"] = per_rank          # K_e imbalance between images = the path's only scaling loss
+    if dist is not None:
+        result["collectives"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_in_world_of_one": bool(force)}
     # PMC passes cannot run inside the timed region (counter collection serialises kernels): the per-launch HBM-side
     # traffic comes from a separate rocprofv3 --pmc run of THIS command (tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json),
     # quoted only when that file was measured on the same kernel sources (csrc_sha16); otherwise null
@@ -454,6 +492,26 @@ def main():
     kv = timer.region_kv_read()
     if kv is not None:
         result["region_attention_kv_read"] = kv
+    if rank == 0 and world == 1 and not args.toy and not os.environ.get("RGN_BENCH_NO_5PCT"):
+        # untimed extra leg: the same edit with K_e = 5 % of the tokens - the case where the region-step attention launch is
+        # bound by the K / V^T cache read rather than by MFMA ("KV-read HBM GB/s in region attention")
+        side5 = int(round((0.05 * L) ** 0.5))
+        b5 = max(side5 - 2, 3)
+        r5 = (h_tok - b5) // 2
+        keep = pipe._bench_target
+        install_region_injection(pipe, h_tok, w_tok, (r5, r5 + b5, r5, r5 + b5), img[0:1], seed=7)
+        edit()                                                   # warm (new K_e: new split plans / tables)
+        t5 = KernelTimer()
+        t5.wrap(ops)
+        tr5 = {}
+        _, sm5 = step_times(tr5)
+        t5.unwrap()
+        s5 = t5.summary()
+        result["region_5pct"] = {"K_e": int(pipe._regione_manager.edited_ids.shape[1]), "step_ms_by_kind": sm5,
+                                 "region_attention_kv_read": t5.region_kv_read(),
+                                 "gemm_tflops": s5.get("gemm_bf16_kernel", {}).get("achieved_tflops"),
+                                 "attention_tflops": s5.get("attention_kernel", {}).get("achieved_tflops")}
+        pipe._bench_target = keep
     if rank == 0 and world == 1 and not args.no_vanilla:
         # full-token denoising on the same engine: the speed-up the reference headlines (README.md:23)
         helper.disable()

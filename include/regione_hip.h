@@ -171,6 +171,29 @@ int rgn_gemm_bf16_qkv_pair(const void* A0, int lda0, const void* W0, const void*
                            void* C1, int ldc1, int M1, const rgn_qkv_epilogue* e1, int N, int K, void* workspace,
                            size_t workspace_bytes, void* stream);
 
+/* Up to FOUR problems with the same N, K, epilogue and weight format in ONE launch: the text and image streams of a double
+ * block for BOTH classifier-free-guidance branches (reference: the B = 2 batched CFG forward, Step1XEdit/inplace.py:381-399;
+ * Step1XEditV1P2/inplace.py:398,416 and QwenImageEdit/inplace.py:371-405 run the branches in sequence - rows of different
+ * branches never interact in a Linear, so one launch computes both).  Each problem keeps its own activations, output,
+ * gate / residual (per-branch AdaLN gates) and - with RGN_EPI_QKV - its own Q/K/V epilogue descriptor (per-branch K / V^T
+ * cache slabs, rotary tables and cache-row lists); problems may share W (streamed from HBM once for both branches).
+ * W is [N, K] contiguous (bf16, or fp8 bytes when `wscale` is set - then for every problem).  M == 0 problems are skipped.
+ * Per output element the accumulation order depends only on the tile geometry and the split-K piece count the planner
+ * picks for the launch, never on which other problems share it. */
+typedef struct rgn_gemm_problem {
+    const void* A;             /* [M, K] bf16, row stride lda */
+    const void* W;             /* [N, K] */
+    const float* wscale;       /* per-output-channel fp32 scale: W is OCP e4m3fn bytes; NULL: W is bf16 */
+    const void* bias;          /* [N] bf16 or NULL */
+    void* C;                   /* [M, N] bf16, row stride ldc */
+    const void* gate;          /* RGN_EPI_GATE_RESID */
+    const void* resid;
+    const rgn_qkv_epilogue* qkv;   /* RGN_EPI_QKV */
+    int lda, ldc, M;
+} rgn_gemm_problem;
+int rgn_gemm_group(const rgn_gemm_problem* probs, int nprob, int N, int K, int epilogue, int gelu_from_col, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
 /* fp8 weights (BASELINE.json configs[4]: "fp8 weights on CDNA4").  The same four GEMM entry points with W stored as OCP
  * e4m3fn bytes ([N, K], ldw in BYTES, a multiple of 16) plus one fp32 scale per output channel (`wscale[N]`, 16-byte
  * aligned): C = epilogue((A @ dequant(W8)^T) * wscale[n] + bias).  Activations, bias, outputs and every epilogue stay
@@ -220,6 +243,13 @@ int rgn_silu_bf16(const void* x, void* y, size_t n, void* stream);
 int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int split_row,
                     const void* shift0, const void* scale0, const void* shift1, const void* scale1,
                     void* stream);
+
+/* The same with up to FOUR row segments: rows [seg_end[i-1], seg_end[i]) use (shift[i], scale[i]); seg_end[nseg-1] == M.
+ * `seg_end_host`, `shift_host`, `scale_host` are HOST arrays (of ints / device pointers) read at call time.  Used by the
+ * batched CFG forward: [text_cond ; image_cond ; text_uncond ; image_uncond] rows with per-stream, per-branch AdaLN vectors
+ * (reference: the B = 2 forward, Step1XEdit/inplace.py:381-399, where `temb` has one row per branch). */
+int rgn_ln_modulate_segs(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int nseg,
+                         const int* seg_end_host, const void* const* shift_host, const void* const* scale_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Region-Instruction KV-cache write (RegoionEFluxAttnProcessor2_0, inplace.py:717-763,792-794):

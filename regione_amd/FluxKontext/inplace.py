@@ -116,11 +116,12 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, guidance_scale=2.5, latents=None, generator=None, output_type="latent",
                  return_dict=True, callback_on_step_end=None, true_cfg_scale: float = 1.0,
-                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, trace: Optional[dict] = None):
+                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, trace: Optional[dict] = None, sigmas=None,
+                 callback_on_step_end_tensor_inputs=("latents",)):
         MANAGER: FluxKontextManager = self._regione_manager
         assert num_inference_steps == MANAGER.inference_step, "num_inference_steps should be equal to 28"
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
-            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps, sigmas)
         timesteps = self.scheduler.timesteps
         guidance = torch.full([1], guidance_scale, dtype=torch.float32)
         MANAGER.refresh(latents, image_latents, latent_ids, text_ids, 2, self.vae_scale_factor, height, width)
@@ -166,8 +167,8 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))
                 trace.setdefault("noise_pred", []).append(noise_pred.clone())
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
-            if callback_on_step_end is not None:
-                callback_on_step_end(self, i, t, {"latents": latents})
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)                  # inplace.py:376-383
             latents, latent_ids = MANAGER.step(latents, latent_ids)
             if trace is not None:
                 trace.setdefault("latents", []).append(latents.clone())
@@ -273,8 +274,17 @@ class RegionEFluxAttnProcessor(H.FluxAttnProcessor):
             pad = ops.padded(skv)
             c = self.caches.get(tag)
             if c is None or c[0].shape[0] != pad:
-                c = (torch.zeros(pad, d, dtype=torch.bfloat16, device=ws.device),
-                     torch.zeros(d, pad, dtype=torch.bfloat16, device=ws.device), skv)
+                # a slab outlives the forward that creates it and is read by both streams later: allocate it under the
+                # DEFAULT stream of the device, so the caching allocator never ties its block to a side stream
+                cur = torch.cuda.current_stream(ws.device)
+                dflt = torch.cuda.default_stream(ws.device)
+                with torch.cuda.stream(dflt):
+                    c = (torch.zeros(pad, d, dtype=torch.bfloat16, device=ws.device),
+                         torch.zeros(d, pad, dtype=torch.bfloat16, device=ws.device), skv)
+                cur.wait_stream(dflt)            # the zero fill is ordered before this forward's writes
+                if cur != dflt:
+                    c[0].record_stream(cur)
+                    c[1].record_stream(cur)
             self.caches[tag] = (c[0], c[1], skv)
             return c[0], c[1], None, skv, None
         # update: only rows [text ; T + edited_ids] are recomputed (:727-750)

@@ -118,6 +118,7 @@ class FluxKontextManager:
         self.edited_ids, self.unedited_ids, self.edited_mask = edited_ids, unedited_ids, mask
         self._ids_edited_host = None
         self._sel_by_T, self._ropeq_by_T = {}, {}
+        self._branch_warm = set()        # the lazily built per-text-length tables are gone: next forward pair runs in order
         self.sel_rows = self.sel_rows_for(self.txt_length)
         if self.image_rotary_emb is not None:
             self.rope_q_region = self.rope_q_for(self.txt_length, self.image_rotary_emb)

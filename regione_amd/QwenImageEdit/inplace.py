@@ -70,11 +70,12 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, negative_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, true_cfg_scale=4.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True, trace: Optional[dict] = None, cond_shapes=None):
+                 return_dict=True, trace: Optional[dict] = None, cond_shapes=None, sigmas=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
         MANAGER = self._regione_manager
         assert num_inference_steps == MANAGER.inference_step, "num_inference_steps should be equal to 28"
         latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps,
-                                                               cond_shapes)
+                                                               cond_shapes, sigmas)
         timesteps = self.scheduler.timesteps
         img_shapes = self._shapes(height, width, cond_shapes)
         do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None           # :238
@@ -125,6 +126,8 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))
                 trace.setdefault("noise_pred", []).append(noise_pred.clone())
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)
             latents, latent_ids = MANAGER.step(latents, latent_ids)
             if trace is not None:
                 trace.setdefault("latents", []).append(latents.clone())

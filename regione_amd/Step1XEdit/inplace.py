@@ -69,12 +69,13 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
                  negative_pooled_prompt_embeds=None, height=1024, width=1024, num_inference_steps=28,
                  true_cfg_scale=6.0, guidance_scale=6.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4, trace: Optional[dict] = None):
+                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4, trace: Optional[dict] = None, sigmas=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
         MANAGER = self._regione_manager
         assert num_inference_steps == MANAGER.inference_step, "inference step mismatch"
         do_true_cfg = true_cfg_scale > 1                                     # :230
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
-            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps, sigmas)
         timesteps = self.scheduler.timesteps
         MANAGER.refresh(latents, image_latents, latent_ids, text_ids, 2, self.vae_scale_factor, height, width)
         avd, cache = fk.AvdState(), None
@@ -110,6 +111,8 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
                 trace.setdefault("kind", []).append("C" if should_cache else ("F" if MANAGER.is_full_input_step() else "R"))
                 trace.setdefault("noise_pred", []).append(noise_pred.clone())
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)
             latents, latent_ids = MANAGER.step(latents, latent_ids)
             if trace is not None:
                 trace.setdefault("latents", []).append(latents.clone())

@@ -32,6 +32,15 @@ class QkvEpilogue(C.Structure):
 
 _qkv_p = C.POINTER(QkvEpilogue)
 
+
+class GemmProblem(C.Structure):
+    """struct rgn_gemm_problem (include/regione_hip.h): one problem of rgn_gemm_group."""
+    _fields_ = [("A", _c_void_p), ("W", _c_void_p), ("wscale", _c_void_p), ("bias", _c_void_p), ("C", _c_void_p),
+                ("gate", _c_void_p), ("resid", _c_void_p), ("qkv", _qkv_p), ("lda", _c_int), ("ldc", _c_int), ("M", _c_int)]
+
+
+_prob_p = C.POINTER(GemmProblem)
+
 # name -> argtypes (restype is always int unless listed in _RESTYPE)
 SIGNATURES = {
     "rgn_version": [],
@@ -50,6 +59,7 @@ SIGNATURES = {
     "rgn_gemm_bf16": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                       _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemm_workspace_bytes": [],
+    "rgn_gemm_group": [_prob_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemm_bf16_qkv": [_c_void_p, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
                           _qkv_p, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_gemm_bf16_qkv_pair": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _qkv_p,
@@ -75,6 +85,8 @@ SIGNATURES = {
     "rgn_silu_bf16": [_c_void_p, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_ln_modulate": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "rgn_ln_modulate_segs": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, C.POINTER(_c_int),
+                             C.POINTER(_c_void_p), C.POINTER(_c_void_p), _c_void_p],
     "rgn_qk_norm_rope_store": [_c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p,
                                _c_void_p, _c_void_p, _c_void_p, _c_float, _c_void_p, _c_void_p, _c_void_p,
                                _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],

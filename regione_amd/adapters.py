@@ -19,7 +19,7 @@ the host's own methods in the order the reference's patched `__call__` does (Reg
 
 diffusers is not installed in the build image: the call sequence follows the reference's copy of the diffusers
 `__call__`, and is exercised in tests/test_adapters.py against host-pipeline stand-ins with the same method surface
-(tools/ref_stubs.py module trees).  Treat the first run against a real checkpoint as the remaining validation step.
+(tests/host_trunks.py module trees, whose own vanilla forward the adopted engine is compared with).  Treat the first run against a real checkpoint as the remaining validation step.
 """
 from __future__ import annotations
 
@@ -169,6 +169,34 @@ def _one_image_only(prompt, num_images_per_prompt):
                          "one image per call, shard images across GPUs")
 
 
+# stock-pipeline arguments the hosted calls take no action on, with the value at which ignoring them changes nothing
+_IGNORABLE_DEFAULTS = {"max_sequence_length": 512, "num_images_per_prompt": 1, "guidance_scale": None, "ip_adapter_image": None,
+                       "ip_adapter_image_embeds": None, "negative_ip_adapter_image": None, "negative_ip_adapter_image_embeds": None,
+                       "joint_attention_kwargs": None, "attention_kwargs": None, "prompt_2": None, "negative_prompt_2": None}
+
+
+def _refuse_unused(fn_name: str, unused: dict):
+    """A stock-pipeline argument the hosted loop does not implement must not be dropped silently (advisor finding, round 2:
+    the reference honours `joint_attention_kwargs`, IP-adapter inputs ... - FluxKontext/inplace.py:76-110): None or the
+    documented default passes, anything else raises."""
+    for k, v in unused.items():
+        if v is None or (k in _IGNORABLE_DEFAULTS and v == _IGNORABLE_DEFAULTS[k]):
+            continue
+        known = k in _IGNORABLE_DEFAULTS
+        raise (NotImplementedError if known else TypeError)(
+            f"{fn_name}: argument {k}={v!r} is {'not implemented by' if known else 'unknown to'} the hosted HIP loop")
+
+
+def _loop_extras(kw: dict, sigmas, callback_on_step_end, callback_on_step_end_tensor_inputs):
+    """`sigmas` (inplace.py:229-242) and `callback_on_step_end` (:376-383) travel to the engine's loop."""
+    if sigmas is not None:
+        kw["sigmas"] = sigmas
+    if callback_on_step_end is not None:
+        kw["callback_on_step_end"] = callback_on_step_end
+        kw["callback_on_step_end_tensor_inputs"] = tuple(callback_on_step_end_tensor_inputs)
+    return kw
+
+
 class _Clock:
     """Wall-clock of the stages of an edit (end-to-end = encode + loop + decode)."""
 
@@ -191,8 +219,10 @@ def _hosted_flux(host, eng, image=None, prompt=None, prompt_2=None, negative_pro
                  num_images_per_prompt: int = 1, generator=None, latents=None, prompt_embeds=None, pooled_prompt_embeds=None,
                  negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, output_type: str = "pil",
                  return_dict: bool = True, max_sequence_length: int = 512, max_area: int = 1024 ** 2, _auto_resize: bool = True,
-                 preferred_resolutions=None, trace=None, **unused):
+                 preferred_resolutions=None, trace=None, sigmas=None, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=("latents",), **unused):
     """FluxKontextPipeline.__call__ around the engine loop (RegionE/FluxKontext/inplace.py:112-240, :396-410)."""
+    _refuse_unused("FluxKontextPipeline.__call__", unused)
     dev = eng.transformer.device
     clk = _Clock(dev)
     multiple_of = host.vae_scale_factor * 2
@@ -241,7 +271,7 @@ def _hosted_flux(host, eng, image=None, prompt=None, prompt_2=None, negative_pro
               negative_pooled_prompt_embeds=_bf(negative_pooled_prompt_embeds, dev) if do_true_cfg else None)
     if trace is not None:
         kw["trace"] = trace
-    latents = eng(**kw)[0]
+    latents = eng(**_loop_extras(kw, sigmas, callback_on_step_end, callback_on_step_end_tensor_inputs))[0]
     clk.mark("loop_s")
     # 7. decode (inplace.py:396-410)
     if output_type == "latent":
@@ -288,9 +318,11 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
                    num_inference_steps: int = 28, guidance_scale: float = 6.0, num_images_per_prompt: int = 1, generator=None,
                    latents=None, prompt_embeds=None, prompt_embeds_mask=None, negative_prompt_embeds=None,
                    negative_prompt_embeds_mask=None, output_type: str = "pil", return_dict: bool = True,
-                   timesteps_truncate: float = 0.93, process_norm_power: float = 0.4, size_level=None, trace=None, **unused):
+                   timesteps_truncate: float = 0.93, process_norm_power: float = 0.4, size_level=None, trace=None, sigmas=None,
+                   callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), **unused):
     """Step1XEditPipeline / Step1XEditPipelineV1P2 `__call__` around the engine loop (Step1XEdit/inplace.py:185-330,:437-455;
     Step1XEditV1P2/inplace.py:214-300).  Not hosted: v1p2's thinking / reflection retry loop (VLM prompting, :192-212)."""
+    _refuse_unused(_host_name(host) + ".__call__", unused)
     v1p2 = _host_name(host).endswith("V1P2")
     dev = eng.transformer.device
     clk = _Clock(dev)
@@ -334,7 +366,7 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
                   process_norm_power=process_norm_power)
         if trace is not None:
             kw["trace"] = trace
-        latents = eng(**kw)[0]
+        latents = eng(**_loop_extras(kw, sigmas, callback_on_step_end, callback_on_step_end_tensor_inputs))[0]
     finally:
         if prev is None:
             tr.__dict__.pop("connector", None)
@@ -367,10 +399,12 @@ def _qwen_dims(target_area, ratio):
 def _hosted_qwen(host, eng, image=None, prompt=None, negative_prompt=None, true_cfg_scale: float = 4.0, height=None, width=None,
                  num_inference_steps: int = 28, guidance_scale=None, num_images_per_prompt: int = 1, generator=None, latents=None,
                  prompt_embeds=None, prompt_embeds_mask=None, negative_prompt_embeds=None, negative_prompt_embeds_mask=None,
-                 output_type: str = "pil", return_dict: bool = True, max_sequence_length: int = 512, trace=None, **unused):
+                 output_type: str = "pil", return_dict: bool = True, max_sequence_length: int = 512, trace=None, sigmas=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), **unused):
     """QwenImageEditPipeline / QwenImageEditPlusPipeline `__call__` around the engine loop (QwenImageEdit/inplace.py:180-330,
     :434-455; QwenImageEditPlus/inplace.py:189-300: a LIST of condition images, each resized twice - 384^2 area for the VLM,
     1024^2 area for the VAE - the last one fixing the output size)."""
+    _refuse_unused(_host_name(host) + ".__call__", unused)
     plus = "Plus" in _host_name(host)
     dev = eng.transformer.device
     clk = _Clock(dev)
@@ -418,7 +452,7 @@ def _hosted_qwen(host, eng, image=None, prompt=None, negative_prompt=None, true_
               return_dict=False, cond_shapes=cond_shapes)
     if trace is not None:
         kw["trace"] = trace
-    latents = eng(**kw)[0]
+    latents = eng(**_loop_extras(kw, sigmas, callback_on_step_end, callback_on_step_end_tensor_inputs))[0]
     clk.mark("loop_s")
     if output_type == "latent":
         out = latents

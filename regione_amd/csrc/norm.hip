@@ -9,17 +9,26 @@ namespace rgn {
 // ------------------------------------------------------------------------------------------------
 // y = bf16(bf16(bf16(LN(x)) * bf16(1 + scale)) + shift), one 256-thread block per row, two-pass stats
 // ------------------------------------------------------------------------------------------------
+// Row segments with their own modulation vectors: rows [end[i-1], end[i]) use (shift[i], scale[i]) - the text / image
+// streams of a double block, times the CFG branches of a batched forward (per-branch AdaLN vectors).
+constexpr int LN_MAXSEG = 4;
+struct LnSegs {
+    int end[LN_MAXSEG];
+    const uint16_t* shift[LN_MAXSEG];
+    const uint16_t* scale[LN_MAXSEG];
+};
+
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const uint16_t* __restrict__ x, int ldx,
                                                           uint16_t* __restrict__ out, int ldo, int d, float eps,
-                                                          int split_row, const uint16_t* __restrict__ shift0,
-                                                          const uint16_t* __restrict__ scale0,
-                                                          const uint16_t* __restrict__ shift1,
-                                                          const uint16_t* __restrict__ scale1) {
+                                                          const LnSegs segs) {
     __shared__ float red[8];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t* xr = x + (size_t)row * ldx;
-    const uint16_t* sh = row < split_row ? shift0 : shift1;
-    const uint16_t* sc = row < split_row ? scale0 : scale1;
+    int si = 0;
+#pragma unroll
+    for (int i = 0; i < LN_MAXSEG - 1; ++i) si += (row >= segs.end[i]) ? 1 : 0;
+    const uint16_t* sh = segs.shift[si];
+    const uint16_t* sc = segs.scale[si];
     const int nvec = d >> 3;
     constexpr int MAXV = 4;                       // d <= 8192
     float v[MAXV][8];
@@ -195,9 +204,36 @@ int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, fl
     if (!x || !out || M < 0 || d <= 0 || (d % 8) || d > 8192 || (ldx % 8) || (ldo % 8) || !shift1 || !scale1)
         return fail(RGN_E_BADARG, "ln_modulate: bad argument");
     if (split_row > 0 && (!shift0 || !scale0)) return fail(RGN_E_BADARG, "ln_modulate: stream-0 modulation missing");
+    LnSegs segs;
+    for (int i = 0; i < LN_MAXSEG; ++i) {
+        segs.end[i] = i == 0 ? (split_row > 0 ? split_row : 0) : M;
+        segs.shift[i] = (const uint16_t*)(i == 0 && split_row > 0 ? shift0 : shift1);
+        segs.scale[i] = (const uint16_t*)(i == 0 && split_row > 0 ? scale0 : scale1);
+    }
     hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
-                       (uint16_t*)out, ldo, d, eps, split_row, (const uint16_t*)shift0, (const uint16_t*)scale0,
-                       (const uint16_t*)shift1, (const uint16_t*)scale1);
+                       (uint16_t*)out, ldo, d, eps, segs);
+    return check_launch("ln_modulate_kernel");
+}
+
+int rgn_ln_modulate_segs(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int nseg, const int* seg_end_host,
+                         const void* const* shift_host, const void* const* scale_host, void* stream) {
+    if (M == 0) return 0;
+    if (!x || !out || M < 0 || d <= 0 || (d % 8) || d > 8192 || (ldx % 8) || (ldo % 8) || nseg < 1 || nseg > LN_MAXSEG ||
+        !seg_end_host || !shift_host || !scale_host)
+        return fail(RGN_E_BADARG, "ln_modulate_segs: bad argument");
+    LnSegs segs;
+    int prev = 0;
+    for (int i = 0; i < LN_MAXSEG; ++i) {
+        const int j = i < nseg ? i : nseg - 1;
+        if (!shift_host[j] || !scale_host[j] || seg_end_host[j] < prev) return fail(RGN_E_BADARG, "ln_modulate_segs: segment table");
+        segs.end[i] = i < nseg - 1 ? seg_end_host[i] : M;
+        segs.shift[i] = (const uint16_t*)shift_host[j];
+        segs.scale[i] = (const uint16_t*)scale_host[j];
+        prev = seg_end_host[j];
+    }
+    if (seg_end_host[nseg - 1] != M) return fail(RGN_E_BADARG, "ln_modulate_segs: the last segment must end at M");
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+                       (uint16_t*)out, ldo, d, eps, segs);
     return check_launch("ln_modulate_kernel");
 }
 

@@ -42,12 +42,14 @@ def init(backend: str, device: Optional[torch.device] = None):
 
 
 def gather_latents(local: Sequence[torch.Tensor], image_ids: Sequence[int], n_images: int, dist=None,
-                   like: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+                   like: Optional[torch.Tensor] = None, force: bool = False) -> List[Optional[torch.Tensor]]:
     """Every rank ends up with the latents of all images, in image order.  Ranks may hold different
     numbers of images (ragged batch, down to NONE when n_images < world size): shorter ranks pad with a dummy that is
     dropped again.  All images must share one latent shape; a rank without images learns it from `like` (a template
     tensor) or, failing that, from rank 0 (one small broadcast) - it must never enter the collective empty-handed."""
-    if dist is None or dist.get_world_size() == 1:
+    # `force`: run the collective even in a world of one (bench.py --force-collectives: RCCL init + all_gather exercised on
+    # a one-GPU box)
+    if dist is None or (dist.get_world_size() == 1 and not force):
         out: List[Optional[torch.Tensor]] = [None] * n_images
         for j, t in zip(image_ids, local):
             out[j] = t
@@ -82,20 +84,22 @@ def gather_latents(local: Sequence[torch.Tensor], image_ids: Sequence[int], n_im
     return out
 
 
-def timed(fn: Callable[[], None], sync: Callable[[], None], dist=None) -> float:
-    """barrier + sync | fn | sync + barrier; returns the MAX elapsed time over ranks (seconds)."""
+def timed(fn: Callable[[], None], sync: Callable[[], None], dist=None, force: bool = False) -> float:
+    """barrier + sync | fn | sync + barrier; returns the MAX elapsed time over ranks (seconds).  `force`: run the barrier
+    and the MAX-reduce in a world of one too."""
+    coll = dist is not None and (dist.get_world_size() > 1 or force)
     sync()
-    if dist is not None and dist.get_world_size() > 1:
+    if coll:
         dist.barrier()
         sync()
     t0 = time.perf_counter()
     fn()
     sync()
-    if dist is not None and dist.get_world_size() > 1:
+    if coll:
         dist.barrier()
         sync()
     el = time.perf_counter() - t0
-    if dist is not None and dist.get_world_size() > 1:
+    if coll:
         t = torch.tensor([el], dtype=torch.float64)
         if dist.get_backend() == "nccl":
             t = t.cuda()
@@ -187,9 +191,13 @@ def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch
     if side is None:
         side = _side_streams[key] = torch.cuda.Stream(device=main.device)
     side.wait_stream(main)                       # fork: everything enqueued so far (latents, caches of earlier steps) is visible
-    pos = run_cond()                             # host order stays cond -> uncond; the GPU runs them side by side
-    with torch.cuda.stream(side):
-        neg = run_uncond()
-    main.wait_stream(side)                       # join before the combine
+    try:
+        pos = run_cond()                         # host order stays cond -> uncond; the GPU runs them side by side
+        with torch.cuda.stream(side):
+            neg = run_uncond()
+    finally:
+        # join ALWAYS: if a branch raised, whatever the side stream already enqueued still reads / writes the shared K/V
+        # caches and workspaces - later main-stream work must not overtake it
+        main.wait_stream(side)
     neg.record_stream(main)
     return pos, neg

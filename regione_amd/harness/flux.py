@@ -74,7 +74,13 @@ class FlowMatchEulerDiscreteScheduler:
             if k.startswith("_"):                 # diffusers bookkeeping (_class_name, _diffusers_version, ...)
                 continue
             if k not in cfg:
-                raise ValueError(f"scheduler config key {k!r} is not implemented by the HIP engine's scheduler")
+                # a key this restatement does not know: harmless while it is switched off (None / False / 0 - a newer
+                # diffusers adding an option at its default must not break enable()), refused once it asks for something
+                if v is None or v is False or v == 0:
+                    import warnings
+                    warnings.warn(f"scheduler config key {k!r}={v!r} is unknown to the HIP engine's scheduler and ignored")
+                    continue
+                raise ValueError(f"scheduler config key {k!r}={v!r} is not implemented by the HIP engine's scheduler")
             if k in self.UNIMPLEMENTED and v:
                 raise ValueError(f"scheduler config {k}={v!r} is not implemented by the HIP engine's scheduler")
             cfg[k] = v
@@ -637,8 +643,17 @@ class FluxTransformer2DModel:
         if not lanes:
             lanes[sid] = self.ws
         if sid not in lanes:
+            # bounded: the first lane (the engine's own) + at most MAX_SIDE_LANES others, least recently used dropped - a host
+            # that calls from short-lived streams must not pin one ~0.5 GB activation set per stream forever
+            side = [k for k in lanes if lanes[k] is not self.ws]
+            while len(side) >= self.MAX_SIDE_LANES:
+                del lanes[side.pop(0)]
             lanes[sid] = Workspace(self.cfg_model, self.device)
+        else:
+            lanes[sid] = lanes.pop(sid) if lanes[sid] is not self.ws else lanes[sid]      # most recently used last
         return lanes[sid]
+
+    MAX_SIDE_LANES = 2
 
     def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict,
              joint_attention_kwargs=None, out_rows=None):
@@ -708,7 +723,8 @@ class FluxKontextPipeline:
     def interrupt(self):
         return self._interrupt
 
-    def prepare(self, image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps):
+    def prepare(self, image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps,
+                sigmas=None):
         dev = self.transformer.device
         h_tok, w_tok = height // (2 * self.vae_scale_factor), width // (2 * self.vae_scale_factor)
         L = h_tok * w_tok
@@ -724,12 +740,25 @@ class FluxKontextPipeline:
         image_ids[:, 0] = 1
         latent_ids = torch.cat([latent_ids, image_ids], dim=0)       # host tensor [2L, 3]
         text_ids = torch.zeros(prompt_embeds.shape[1], 3)
-        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps)
+        # inplace.py:229: a caller-provided sigma schedule replaces the linspace (its length must be num_inference_steps)
+        sigmas = np.linspace(1.0, 1 / num_inference_steps, num_inference_steps) if sigmas is None else np.asarray(sigmas, dtype=np.float64)
+        if len(sigmas) != num_inference_steps:
+            raise ValueError(f"`sigmas` has {len(sigmas)} entries, num_inference_steps = {num_inference_steps}")
         mu = calculate_shift(L, self.scheduler.config.get("base_image_seq_len", 256),
                              self.scheduler.config.get("max_image_seq_len", 4096),
                              self.scheduler.config.get("base_shift", 0.5), self.scheduler.config.get("max_shift", 1.15))
         self.scheduler.set_timesteps(sigmas=sigmas, mu=mu)
         return latents, image_latents, latent_ids, text_ids, h_tok, w_tok
+
+    def _callback(self, cb, names, i, t, latents, prompt_embeds):
+        """`callback_on_step_end` with the reference's semantics (inplace.py:376-383): called with the tensors named in
+        `callback_on_step_end_tensor_inputs`; `latents` / `prompt_embeds` in the returned dict replace the loop's."""
+        if cb is None:
+            return latents, prompt_embeds
+        avail = {"latents": latents, "prompt_embeds": prompt_embeds}
+        out = cb(self, i, t, {k: avail[k] for k in names})
+        out = dict(out) if out else {}
+        return out.pop("latents", latents), out.pop("prompt_embeds", prompt_embeds)
 
     def _precompute(self, timesteps, guidance, dtype, *pooled_list):
         if hasattr(self.transformer, "precompute_modulations"):
@@ -742,9 +771,10 @@ class FluxKontextPipeline:
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, guidance_scale=2.5, latents=None, generator=None, output_type="latent",
                  return_dict=True, callback_on_step_end=None, true_cfg_scale: float = 1.0,
-                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None):
+                 negative_prompt_embeds=None, negative_pooled_prompt_embeds=None, sigmas=None,
+                 callback_on_step_end_tensor_inputs=("latents",)):
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
-            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps, sigmas)
         timesteps = self.scheduler.timesteps
         guidance = torch.full([1], guidance_scale, dtype=torch.float32)
         do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None
@@ -768,8 +798,8 @@ class FluxKontextPipeline:
                                        img_ids=latent_ids, return_dict=False)[0][:, : latents.size(1)]
                 noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
-            if callback_on_step_end is not None:
-                callback_on_step_end(self, i, t, {"latents": latents})
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)
         if not return_dict:
             return (latents,)
         return FluxPipelineOutput(images=latents)

@@ -112,7 +112,7 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
             return [[s, s]]
         return [[s] + [(1, int(h), int(w)) for h, w in cond_shapes]]
 
-    def prepare_qwen(self, image, height, width, latents, generator, num_inference_steps, cond_shapes=None):
+    def prepare_qwen(self, image, height, width, latents, generator, num_inference_steps, cond_shapes=None, sigmas=None):
         """`image`: packed condition latents [1, L_c, 64], or a list of them (one per condition image, in order)."""
         if isinstance(image, (list, tuple)):
             if cond_shapes is not None:
@@ -122,16 +122,17 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
             assert sum(int(h) * int(w) for h, w in cond_shapes) == image.shape[1], "cond_shapes do not cover the condition latents"
         dummy = torch.zeros(1, 1, 1)
         latents, image_latents, _, _, h_tok, w_tok = self.prepare(image, dummy, None, height, width, latents, generator,
-                                                                  num_inference_steps)
+                                                                  num_inference_steps, sigmas)
         latent_ids = torch.arange(latents.shape[1] + image_latents.shape[1])           # :322
         return latents, image_latents, latent_ids
 
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, negative_prompt_embeds=None, height=1024, width=1024,
                  num_inference_steps=28, true_cfg_scale=4.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True, cond_shapes=None):
+                 return_dict=True, cond_shapes=None, sigmas=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
         latents, image_latents, latent_ids = self.prepare_qwen(image, height, width, latents, generator, num_inference_steps,
-                                                               cond_shapes)
+                                                               cond_shapes, sigmas)
         timesteps = self.scheduler.timesteps
         img_shapes = self._shapes(height, width, cond_shapes)
         do_true_cfg = true_cfg_scale > 1 and negative_prompt_embeds is not None
@@ -153,6 +154,8 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
             else:
                 noise_pred = branch(prompt_embeds, "cond")
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)
         if not return_dict:
             return (latents,)
         return QwenImagePipelineOutput(images=latents)

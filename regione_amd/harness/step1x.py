@@ -90,9 +90,10 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
                  negative_pooled_prompt_embeds=None, height=1024, width=1024, num_inference_steps=28,
                  true_cfg_scale=6.0, guidance_scale=6.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4):
+                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4, sigmas=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
-            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps, sigmas)
         timesteps = self.scheduler.timesteps
         self.scheduler.set_begin_index(0)
         tr = self.transformer
@@ -109,6 +110,8 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
             noise_pred = noise_pred[:, : latents.size(1)]
             noise_pred = self._cfg(noise_pred, t, true_cfg_scale, timesteps_truncate, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)
         if not return_dict:
             return (latents,)
         return Step1XEditPipelineOutput(images=latents)
@@ -121,9 +124,10 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
                  negative_pooled_prompt_embeds=None, height=1024, width=1024, num_inference_steps=28,
                  true_cfg_scale=6.0, guidance_scale=6.0, latents=None, generator=None, output_type="latent",
-                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4):
+                 return_dict=True, timesteps_truncate=0.93, process_norm_power=0.4, sigmas=None,
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
         latents, image_latents, latent_ids, text_ids, _, _ = self.prepare(
-            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps)
+            image, prompt_embeds, pooled_prompt_embeds, height, width, latents, generator, num_inference_steps, sigmas)
         neg_text_ids = torch.zeros(negative_prompt_embeds.shape[1], 3)
         timesteps = self.scheduler.timesteps
         self.scheduler.set_begin_index(0)
@@ -143,6 +147,8 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
             mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN
             noise_pred = TO.R.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
+            latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
+                                                    prompt_embeds)
         if not return_dict:
             return (latents,)
         return Step1XEditPipelineOutput(images=latents)

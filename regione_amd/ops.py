@@ -150,15 +150,28 @@ def cfg_combine(pos: torch.Tensor, neg: torch.Tensor, scale: float, mode: int = 
 # MMDiT block kernels
 # ---------------------------------------------------------------------------------------------
 _gemm_ws = {}
+MAX_WS_LANES = 4          # scratch lanes kept per kind (device x stream), least recently used dropped
+
+
+def _ws_lane(table: dict, device, make):
+    """One scratch buffer per (device, stream), bounded LRU: two forwards running on two streams must not share split-K /
+    KV-split partials, and a host calling from many short-lived streams must not pin 256 + 128 MiB per stream forever.  A
+    dropped lane's memory goes back to the caching allocator, which keeps it off limits until the work enqueued on its
+    stream has finished."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    buf = table.pop(key, None)
+    if buf is None:
+        while len(table) >= MAX_WS_LANES:
+            table.pop(next(iter(table)))
+        buf = make()
+    table[key] = buf                     # most recently used last
+    return buf
 
 
 def gemm_workspace(device) -> torch.Tensor:
-    """fp32 scratch for the round-aware GEMM schedule (allocated once per device and stream: two forwards running on
-    two streams must not share split-K partials)."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    if key not in _gemm_ws:
-        _gemm_ws[key] = torch.empty(_lib.lib().rgn_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device)
-    return _gemm_ws[key]
+    """fp32 scratch for the round-aware GEMM schedule (one per device and stream, see _ws_lane)."""
+    return _ws_lane(_gemm_ws, device,
+                    lambda: torch.empty(_lib.lib().rgn_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device))
 
 
 FP8 = torch.float8_e4m3fn
@@ -286,6 +299,40 @@ def gemm_qkv_pair(A0, W0, b0, out0, epi0, A1, W1, b1, out1, epi1):
     _lib.check(rc, "rgn_gemm_bf16_qkv_pair")
 
 
+class Problem:
+    """One problem of `gemm_group`: out = epilogue(A @ W^T + bias) with its own gate / residual or Q/K/V epilogue."""
+    __slots__ = ("A", "W", "bias", "out", "gate", "resid", "epi")
+
+    def __init__(self, A, W, bias, out, gate=None, resid=None, epi=None):
+        self.A, self.W, self.bias, self.out, self.gate, self.resid, self.epi = A, W, bias, out, gate, resid, epi
+
+
+def gemm_group(problems, *, epilogue: int = EPI_BIAS, gelu_from_col: int = 0):
+    """Up to four GEMMs with equal (N, K), epilogue and weight format in ONE launch (rgn_gemm_group): the text / image
+    streams of a double block x the cond / uncond CFG branches.  Problems may share W."""
+    import ctypes as C
+    probs = [p for p in problems if p.A.shape[0] > 0]
+    if not probs:
+        return
+    assert len(probs) <= 4
+    N, K = probs[0].W.shape
+    arr = (_lib.GemmProblem * len(probs))()
+    for i, p in enumerate(probs):
+        assert p.W.shape == (N, K) and p.W.is_contiguous() and p.A.shape[1] == K and p.out.shape == (p.A.shape[0], N)
+        for t in (p.A, p.out):
+            assert t.stride(1) == 1 and t.dtype == torch.bfloat16
+        if p.resid is not None:
+            assert p.resid.stride(0) == p.out.stride(0) and p.resid.stride(1) == 1
+        g = arr[i]
+        g.A, g.W, g.wscale, g.bias, g.C = _p(p.A), _p(p.W), _p(_wscale(p.W)), _p(p.bias), _p(p.out)
+        g.gate, g.resid = _p(p.gate), _p(p.resid)
+        g.qkv = C.pointer(p.epi) if p.epi is not None else None
+        g.lda, g.ldc, g.M = p.A.stride(0), p.out.stride(0), p.A.shape[0]
+    ws = gemm_workspace(probs[0].A.device)
+    rc = _lib.lib().rgn_gemm_group(arr, len(probs), N, K, epilogue, gelu_from_col, _p(ws), ws.numel() * 4, _stream())
+    _lib.check(rc, "rgn_gemm_group")
+
+
 def gemv(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], silu_input: bool = False,
          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, K = x.shape
@@ -323,6 +370,21 @@ def ln_modulate(x: torch.Tensor, out: torch.Tensor, shift1, scale1, split_row: i
     return out
 
 
+def ln_modulate_segs(x: torch.Tensor, out: torch.Tensor, segs, eps: float = 1e-6) -> torch.Tensor:
+    """LN * (1 + scale) + shift with up to four row segments: `segs` = [(end_row, shift, scale), ...], ascending, the last
+    end_row == rows of x."""
+    import ctypes as C
+    M, d = x.shape
+    n = len(segs)
+    assert 1 <= n <= 4 and segs[-1][0] == M
+    ends = (C.c_int * n)(*[int(s[0]) for s in segs])
+    sh = (C.c_void_p * n)(*[_p(s[1]) for s in segs])
+    sc = (C.c_void_p * n)(*[_p(s[2]) for s in segs])
+    rc = _lib.lib().rgn_ln_modulate_segs(_p(x), x.stride(0), _p(out), out.stride(0), M, d, eps, n, ends, sh, sc, _stream())
+    _lib.check(rc, "rgn_ln_modulate_segs")
+    return out
+
+
 def qk_norm_rope_store(qkv: torch.Tensor, k_col: int, v_col: int, q_col: int, H: int, wq1, wk1, rope_q, rope_k,
                        k_slab: torch.Tensor, vt_slab: torch.Tensor, kv_rows: Optional[torch.Tensor] = None,
                        split_row: int = 0, wq0=None, wk0=None, eps: float = 1e-6):
@@ -341,11 +403,8 @@ _attn_ws = {}
 
 def attention_workspace(device) -> torch.Tensor:
     """fp32 scratch for the round-aware attention schedule (allocated once per device and stream)."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-    if key not in _attn_ws:
-        n = _lib.lib().rgn_attention_workspace_bytes(0, 0)
-        _attn_ws[key] = torch.empty(n // 4, dtype=torch.float32, device=device)
-    return _attn_ws[key]
+    return _ws_lane(_attn_ws, device,
+                    lambda: torch.empty(_lib.lib().rgn_attention_workspace_bytes(0, 0) // 4, dtype=torch.float32, device=device))
 
 
 def attention(q: torch.Tensor, k_slab: torch.Tensor, vt_slab: torch.Tensor, out: torch.Tensor, skv: int, H: int,

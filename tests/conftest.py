@@ -15,6 +15,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu`-marked tests need a HIP device: skipped (not failed) on a box without one, whatever -m says."""
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs a HIP GPU (torch.cuda.is_available() is False)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     """npz -> dict of torch tensors / numpy scalars; '__bf16' / '__f16' keys are bit patterns."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

@@ -2,7 +2,8 @@
 SURFACE the reference's patched `__call__`s use outside the denoise loop (FluxKontext/inplace.py:112-240,:396-410;
 Step1XEdit/inplace.py:185-330,:437-455; Step1XEditV1P2/inplace.py:214-300; QwenImageEdit/inplace.py:180-330,:434-455;
 QwenImageEditPlus/inplace.py:189-300).  diffusers is not installable in this image: the transformer
-trunks are the torch.nn module trees of tools/ref_stubs.py (host parameter naming), everything else is a small
+trunks are the torch.nn module trees of tests/host_trunks.py (host parameter naming, with their own vanilla forwards and
+stock attention processors), everything else is a small
 deterministic toy (16-channel 8x 'VAE', hash-seeded 'prompt encoders', a timestep-dependent Step1X 'connector').
 Test infrastructure only.
 """
@@ -12,14 +13,15 @@ import sys
 import torch
 import torch.nn as nn
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def stub_trunk(family):
-    import ref_stubs as RS
+    """A host transformer as `from_pretrained` would hand it over: host parameter names (Qwen: img_mod / txt_mod / img_mlp /
+    txt_mlp / img_in / txt_in), stock attention processors installed, its own `forward` runnable on the CPU."""
+    import host_trunks as HT
     torch.manual_seed(3)
-    mod = {"flux": RS.FluxTransformer2DModel, "step1x": RS.Step1XEditTransformer2DModel, "qwen": RS.QwenImageTransformer2DModel}[family]()
+    mod = {"flux": HT.FluxTransformer2DModel, "step1x": HT.Step1XEditTransformer2DModel, "qwen": HT.QwenImageHostTransformer2DModel}[family]()
     with torch.no_grad():
         for n, p in mod.named_parameters():
             if p.dim() == 1 and not n.endswith("bias"):
@@ -28,7 +30,7 @@ def stub_trunk(family):
                 p.copy_(0.01 * torch.randn_like(p))
             else:
                 p.copy_(0.05 * torch.randn_like(p))
-    return mod.to(torch.bfloat16)
+    return HT.install_vanilla_processors(mod.to(torch.bfloat16))
 
 
 class ToyConnector(nn.Module):

@@ -127,6 +127,26 @@ def test_bench_two_ranks_share_the_gpu(extra):
     assert abs(d["value"] - 28 * 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
 
 
+def test_bench_one_rank_executes_rccl_init_all_gather_and_max_reduce():
+    """RCCL on hardware without a multi-GPU node: bench.py under torch.distributed.run with ONE rank, backend nccl (= RCCL on
+    ROCm), `--force-collectives` -> process-group init on cuda:0, the barrier pair, the all_gather of the final latents inside
+    the timed region and the MAX all_reduce of the elapsed time all execute; the line reports the backend it ran on."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29950 + (os.getpid() % 40)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--toy", "--dist-backend", "nccl",
+           "--force-collectives", "--no-cpu-baseline", "--no-vanilla"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["collectives"] == {"backend": "nccl", "world": 1, "forced_in_world_of_one": True}
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["steps"] == 2
+
+
 def test_bench_json_contract_single_gpu():
     """`python bench.py` prints exactly one JSON line with the fields the driver and SURVEY.md section 8(d) ask for (toy trunk
     so that the CPU-baseline leg takes seconds; the field set does not depend on the size)."""

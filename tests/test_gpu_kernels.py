@@ -631,3 +631,153 @@ def test_gemm_fp8_weights_widened_once_bit_identical_to_fp8_tiles(M, N, K, epi, 
         outs.append(o)
     assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
     assert torch.isfinite(outs[0].float()).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 3: up to four problems per launch (text / image stream x cond / uncond CFG branch), segmented LN-modulate
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+def test_gemm_group_four_problems_shared_weights_identical_to_separate_launches(variant, monkeypatch):
+    """[image_cond, image_uncond] share W0, [text_cond, text_uncond] share W1; per-problem gate / residual.  Small shapes
+    take no split-K path, so every output element sees the same accumulation order as in a launch of its own."""
+    from regione_amd import ops
+    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    g = torch.Generator().manual_seed(19)
+    N, K = 384, 256
+    Ms = [700, 650, 90, 77]
+    As = [bf(torch.randn(m, K, generator=g)).cuda() for m in Ms]
+    W0, W1 = bf(torch.randn(N, K, generator=g) * 0.1).cuda(), bf(torch.randn(N, K, generator=g) * 0.1).cuda()
+    b0, b1 = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+    Ws, bs = [W0, W0, W1, W1], [b0, b0, b1, b1]
+    gates = [bf(torch.randn(N, generator=g)).cuda() for _ in Ms]
+    res = [bf(torch.randn(m, N, generator=g)).cuda() for m in Ms]
+    outs = [torch.empty_like(r) for r in res]
+    ops.gemm_group([ops.Problem(a, w, b, o) for a, w, b, o in zip(As, Ws, bs, outs)])
+    for a, w, b, o in zip(As, Ws, bs, outs):
+        s = torch.empty_like(o)
+        ops.gemm(a, w, b, s)
+        assert torch.equal(o, s)
+    assert rel_err(outs[1].cpu(), F.linear(As[1].cpu().double(), W0.cpu().double(), b0.cpu().double())) < 3e-3
+    xs = [r.clone() for r in res]
+    ops.gemm_group([ops.Problem(a, w, b, x, gate=gt, resid=x) for a, w, b, x, gt in zip(As, Ws, bs, xs, gates)],
+                   epilogue=ops.EPI_GATE_RESID)
+    for a, w, b, r, gt, x in zip(As, Ws, bs, res, gates, xs):
+        y = r.clone()
+        ops.gemm(a, w, b, y, epilogue=ops.EPI_GATE_RESID, gate=gt, resid=y)
+        assert torch.equal(x, y)
+    # three problems, one of them empty; GELU epilogue
+    o3 = [torch.empty_like(r) for r in res[:3]]
+    ops.gemm_group([ops.Problem(As[0], W0, b0, o3[0]), ops.Problem(As[1][:0], W0, b0, o3[1][:0]), ops.Problem(As[2], W1, b1, o3[2])],
+                   epilogue=ops.EPI_GELU)
+    for i in (0, 2):
+        s = torch.empty_like(o3[i])
+        ops.gemm(As[i], Ws[i], bs[i], s, epilogue=ops.EPI_GELU)
+        assert torch.equal(o3[i], s)
+
+
+@pytest.mark.parametrize("split", ["0", None])
+def test_gemm_group_region_step_shapes_of_two_cfg_branches(split, monkeypatch):
+    """The region-step shapes of a batched CFG forward at FLUX / Qwen dimensions: image rows 1024 + 1024, text rows
+    512 + 384, K = 3072 -> N = 12288 (ff1) and K = 12288 -> N = 3072 (ff2, gated residual).  Without the split-K schedule
+    (RGN_GEMM_SPLIT=0) the group is bit-identical to per-branch pair launches; with it the piece count may differ between
+    the two launch shapes (fp32 summation order), so the comparison is against a float64 reference."""
+    from regione_amd import ops
+    if split is not None:
+        monkeypatch.setenv("RGN_GEMM_SPLIT", split)
+    g = torch.Generator().manual_seed(23)
+    d, ff = 3072, 12288
+    Mi, Ts = 1024, (512, 384)
+    Wi, Wt = bf(torch.randn(ff, d, generator=g) * 0.02).cuda(), bf(torch.randn(ff, d, generator=g) * 0.02).cuda()
+    bi, bt = bf(torch.randn(ff, generator=g) * 0.01).cuda(), bf(torch.randn(ff, generator=g) * 0.01).cuda()
+    Ai = [bf(torch.randn(Mi, d, generator=g)).cuda() for _ in Ts]
+    At = [bf(torch.randn(t, d, generator=g)).cuda() for t in Ts]
+    hi = [torch.empty(Mi, ff, dtype=torch.bfloat16, device="cuda") for _ in Ts]
+    ht = [torch.empty(t, ff, dtype=torch.bfloat16, device="cuda") for t in Ts]
+    ops.gemm_group([ops.Problem(Ai[0], Wi, bi, hi[0]), ops.Problem(At[0], Wt, bt, ht[0]),
+                    ops.Problem(Ai[1], Wi, bi, hi[1]), ops.Problem(At[1], Wt, bt, ht[1])], epilogue=ops.EPI_GELU)
+    for b in range(2):
+        si, st_ = torch.empty_like(hi[b]), torch.empty_like(ht[b])
+        ops.gemm_pair(Ai[b], Wi, bi, si, At[b], Wt, bt, st_, epilogue=ops.EPI_GELU)
+        if split == "0":
+            assert torch.equal(hi[b], si) and torch.equal(ht[b], st_)
+        ref = F.gelu(F.linear(At[b].cpu().double(), Wt.cpu().double(), bt.cpu().double()), approximate="tanh")
+        assert rel_err(ht[b].cpu(), ref) < 4e-3
+    # ff2 with the gated residual (long K: the shape the planner splits)
+    W2i, W2t = bf(torch.randn(d, ff, generator=g) * 0.02).cuda(), bf(torch.randn(d, ff, generator=g) * 0.02).cuda()
+    b2 = bf(torch.randn(d, generator=g) * 0.01).cuda()
+    gates = [bf(torch.randn(d, generator=g)).cuda() for _ in range(4)]
+    xi = [bf(torch.randn(Mi, d, generator=g)).cuda() for _ in Ts]
+    xt = [bf(torch.randn(t, d, generator=g)).cuda() for t in Ts]
+    yi, yt = [x.clone() for x in xi], [x.clone() for x in xt]
+    ops.gemm_group([ops.Problem(hi[0], W2i, b2, yi[0], gate=gates[0], resid=yi[0]), ops.Problem(ht[0], W2t, b2, yt[0], gate=gates[1], resid=yt[0]),
+                    ops.Problem(hi[1], W2i, b2, yi[1], gate=gates[2], resid=yi[1]), ops.Problem(ht[1], W2t, b2, yt[1], gate=gates[3], resid=yt[1])],
+                   epilogue=ops.EPI_GATE_RESID)
+    for b in range(2):
+        zi, zt = xi[b].clone(), xt[b].clone()
+        ops.gemm_pair(hi[b], W2i, b2, zi, ht[b], W2t, b2, zt, epilogue=ops.EPI_GATE_RESID, gate0=gates[2 * b], resid0=zi,
+                      gate1=gates[2 * b + 1], resid1=zt)
+        if split == "0":
+            assert torch.equal(yi[b], zi) and torch.equal(yt[b], zt)
+        lin = F.linear(ht[b].cpu().double(), W2t.cpu().double(), b2.cpu().double())
+        ref = xt[b].cpu().double() + gates[2 * b + 1].cpu().double() * lin
+        assert rel_err(yt[b].cpu(), ref) < 4e-3
+        assert rel_err(yi[b].cpu(), zi.cpu().double()) < 2e-3
+
+
+def test_gemm_group_fused_qkv_epilogue_per_branch_slabs():
+    """Q/K/V epilogue with one descriptor per problem: two CFG branches (text lengths 48 / 40) write their own K / V^T slabs
+    and take their own rotary rows; bit-identical to one gemm_qkv_pair launch per branch."""
+    from regione_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    H, K, Mi = 2, 256, 400
+    D, N = H * 128, 3 * H * 128
+    Ts = (48, 40)
+    Ai0, W0, b0, wq0, wk0, _, _, _, _ = _qkv_case(Mi, H, K, 0, gen, skv=Ts[0] + Mi)
+    At0, W1, b1, wq1, wk1, _, _, _, _ = _qkv_case(Ts[0], H, K, 0, gen)
+    Ai = [Ai0, bf(torch.randn(Mi, K, generator=gen)).cuda()]
+    At = [At0, bf(torch.randn(Ts[1], K, generator=gen)).cuda()]
+    ropes = []
+    for T in Ts:
+        ang = torch.rand(T + Mi, 64, generator=gen) * 6.28
+        ropes.append((ang.cos().repeat_interleave(2, 1).contiguous().cuda(), ang.sin().repeat_interleave(2, 1).contiguous().cuda()))
+    grp_out, ref_out, grp_slabs, ref_slabs, probs = [], [], [], [], []
+    for b, T in enumerate(Ts):
+        pad = ops.padded(T + Mi)
+        for outs, slabs in ((grp_out, grp_slabs), (ref_out, ref_slabs)):
+            outs.append(torch.zeros(T + Mi, N, dtype=torch.bfloat16, device="cuda"))
+            slabs.append((torch.zeros(pad, D, dtype=torch.bfloat16, device="cuda"), torch.zeros(D, pad, dtype=torch.bfloat16, device="cuda")))
+        common = dict(rope_q=ropes[b], rope_k=ropes[b], H=H, k_col=0, v_col=D, q_col=2 * D)
+        e_i = ops.qkv_epilogue(wq=wq0, wk=wk0, row_base=T, k_slab=grp_slabs[b][0], vt_slab=grp_slabs[b][1], **common)
+        e_t = ops.qkv_epilogue(wq=wq1, wk=wk1, row_base=0, k_slab=grp_slabs[b][0], vt_slab=grp_slabs[b][1], **common)
+        probs += [ops.Problem(Ai[b], W0, b0, grp_out[b][T:], epi=e_i), ops.Problem(At[b], W1, b1, grp_out[b][:T], epi=e_t)]
+        ops.gemm_qkv_pair(Ai[b], W0, b0, ref_out[b][T:], ops.qkv_epilogue(wq=wq0, wk=wk0, row_base=T, k_slab=ref_slabs[b][0],
+                                                                        vt_slab=ref_slabs[b][1], **common),
+                          At[b], W1, b1, ref_out[b][:T], ops.qkv_epilogue(wq=wq1, wk=wk1, row_base=0, k_slab=ref_slabs[b][0],
+                                                                        vt_slab=ref_slabs[b][1], **common))
+    ops.gemm_group(probs, epilogue=3)
+    for b in range(2):
+        assert torch.equal(grp_out[b][:, 2 * D:], ref_out[b][:, 2 * D:])
+        assert torch.equal(grp_slabs[b][0], ref_slabs[b][0]) and torch.equal(grp_slabs[b][1], ref_slabs[b][1])
+        assert float(grp_slabs[b][0].float().abs().sum()) > 0
+
+
+def test_ln_modulate_four_segments():
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(31)
+    d = 3072
+    ends = [40, 300, 332, 600]
+    x = bf(torch.randn(ends[-1], d, generator=g) * 2 + 0.3)
+    mods = [(bf(torch.randn(d, generator=g) * 0.5), bf(torch.randn(d, generator=g) * 0.5)) for _ in ends]
+    out = torch.empty(ends[-1], d, dtype=torch.bfloat16).cuda()
+    ops.ln_modulate_segs(x.cuda(), out, [(e, sh.cuda(), sc.cuda()) for e, (sh, sc) in zip(ends, mods)])
+    lo = 0
+    for e, (sh, sc) in zip(ends, mods):
+        one = torch.empty(e - lo, d, dtype=torch.bfloat16).cuda()
+        ops.ln_modulate(x[lo:e].cuda(), one, sh.cuda(), sc.cuda())
+        assert torch.equal(out[lo:e], one)                       # a segment == the two-set kernel on those rows
+        lo = e
+    two = torch.empty_like(out)
+    ops.ln_modulate_segs(x.cuda(), two, [(ends[0], mods[0][0].cuda(), mods[0][1].cuda()), (ends[-1], mods[1][0].cuda(), mods[1][1].cuda())])
+    ref = torch.empty_like(out)
+    ops.ln_modulate(x.cuda(), ref, mods[1][0].cuda(), mods[1][1].cuda(), split_row=ends[0], shift0=mods[0][0].cuda(), scale0=mods[0][1].cuda())
+    assert torch.equal(two, ref)

@@ -37,424 +37,35 @@ import torch.nn.functional as F
 REF_ROOT = "/root/reference"
 
 
-# --------------------------------------------------------------------------------------
-# [EXT] diffusers restatements (upstream semantics, used only to host the reference on CPU)
-# --------------------------------------------------------------------------------------
-def apply_rotary_emb(x, freqs_cis, use_real=True, use_real_unbind_dim=-1, sequence_dim=2):
-    """[EXT] diffusers.models.embeddings.apply_rotary_emb, use_real / unbind_dim=-1 branch.
-    x: [B, H, S, D]; freqs_cis = (cos, sin) each [S, D]."""
-    cos, sin = freqs_cis
-    cos = cos[None, None].to(x.device)
-    sin = sin[None, None].to(x.device)
-    x_real, x_imag = x.reshape(*x.shape[:-1], -1, 2).unbind(-1)
-    x_rotated = torch.stack([-x_imag, x_real], dim=-1).flatten(3)
-    return (x.float() * cos + x_rotated.float() * sin).to(x.dtype)
-
-
-def get_1d_rotary_pos_embed(dim, pos, theta=10000.0):
-    """[EXT] repeat_interleave_real=True, use_real=True, freqs_dtype=float64 branch."""
-    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.float64)[: dim // 2] / dim))
-    freqs = torch.outer(pos.to(torch.float64), freqs)
-    cos = freqs.cos().repeat_interleave(2, dim=1).float()
-    sin = freqs.sin().repeat_interleave(2, dim=1).float()
-    return cos, sin
-
-
-class FluxPosEmbed(nn.Module):
-    """[EXT] diffusers FluxPosEmbed: ids [S, n_axes] -> (cos, sin) [S, sum(axes_dim)]."""
-
-    def __init__(self, theta=10000, axes_dim=(16, 56, 56)):
-        super().__init__()
-        self.theta = theta
-        self.axes_dim = tuple(axes_dim)
-
-    def forward(self, ids):
-        n_axes = ids.shape[-1]
-        cos_out, sin_out = [], []
-        pos = ids.float()
-        for i in range(n_axes):
-            cos, sin = get_1d_rotary_pos_embed(self.axes_dim[i], pos[:, i], theta=self.theta)
-            cos_out.append(cos)
-            sin_out.append(sin)
-        return torch.cat(cos_out, dim=-1).to(ids.device), torch.cat(sin_out, dim=-1).to(ids.device)
-
-
-class RMSNorm(nn.Module):
-    """[EXT] diffusers.models.normalization.RMSNorm (elementwise_affine=True, no bias)."""
-
-    def __init__(self, dim, eps=1e-6):
-        super().__init__()
-        self.eps = eps
-        self.weight = nn.Parameter(torch.ones(dim))
-
-    def forward(self, hidden_states):
-        input_dtype = hidden_states.dtype
-        variance = hidden_states.to(torch.float32).pow(2).mean(-1, keepdim=True)
-        hidden_states = hidden_states * torch.rsqrt(variance + self.eps)
-        if self.weight.dtype in (torch.float16, torch.bfloat16):
-            hidden_states = hidden_states.to(self.weight.dtype)
-        hidden_states = hidden_states * self.weight
-        return hidden_states.to(input_dtype) if self.weight.dtype == input_dtype else hidden_states
-
-
-class AdaLayerNormZero(nn.Module):
-    """[EXT] 6-way AdaLN-Zero used by FluxTransformerBlock."""
-
-    def __init__(self, dim):
-        super().__init__()
-        self.silu = nn.SiLU()
-        self.linear = nn.Linear(dim, 6 * dim, bias=True)
-        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
-
-    def forward(self, x, emb=None):
-        emb = self.linear(self.silu(emb))
-        shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
-        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
-        return x, gate_msa, shift_mlp, scale_mlp, gate_mlp
-
-
-class AdaLayerNormZeroSingle(nn.Module):
-    """[EXT] 3-way AdaLN-Zero used by FluxSingleTransformerBlock."""
-
-    def __init__(self, dim):
-        super().__init__()
-        self.silu = nn.SiLU()
-        self.linear = nn.Linear(dim, 3 * dim, bias=True)
-        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
-
-    def forward(self, x, emb=None):
-        emb = self.linear(self.silu(emb))
-        shift_msa, scale_msa, gate_msa = emb.chunk(3, dim=1)
-        x = self.norm(x) * (1 + scale_msa[:, None]) + shift_msa[:, None]
-        return x, gate_msa
-
-
-class AdaLayerNormContinuous(nn.Module):
-    """[EXT] norm_out of FluxTransformer2DModel (elementwise_affine=False, eps=1e-6)."""
-
-    def __init__(self, dim, cond_dim):
-        super().__init__()
-        self.silu = nn.SiLU()
-        self.linear = nn.Linear(cond_dim, 2 * dim, bias=True)
-        self.norm = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
-
-    def forward(self, x, conditioning_embedding):
-        emb = self.linear(self.silu(conditioning_embedding).to(x.dtype))
-        scale, shift = torch.chunk(emb, 2, dim=1)
-        return self.norm(x) * (1 + scale)[:, None, :] + shift[:, None, :]
-
-
-class _GELUProj(nn.Module):
-    def __init__(self, dim_in, dim_out):
-        super().__init__()
-        self.proj = nn.Linear(dim_in, dim_out, bias=True)
-
-    def forward(self, x):
-        return F.gelu(self.proj(x), approximate="tanh")
-
-
-class FeedForward(nn.Module):
-    """[EXT] diffusers FeedForward(activation_fn='gelu-approximate', mult=4)."""
-
-    def __init__(self, dim, mult=4):
-        super().__init__()
-        self.net = nn.ModuleList([_GELUProj(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim)])
-
-    def forward(self, x):
-        for m in self.net:
-            x = m(x)
-        return x
-
-
-class Attention(nn.Module):
-    """[EXT] the attribute container the reference's processors expect
-    (RegionE/FluxKontext/inplace.py:715-820) plus set_processor / forward dispatch."""
-
-    def __init__(self, dim, heads, head_dim, added_kv=False, pre_only=False, processor=None):
-        super().__init__()
-        self.heads = heads
-        inner = heads * head_dim
-        self.to_q = nn.Linear(dim, inner, bias=True)
-        self.to_k = nn.Linear(dim, inner, bias=True)
-        self.to_v = nn.Linear(dim, inner, bias=True)
-        self.norm_q = RMSNorm(head_dim, eps=1e-6)
-        self.norm_k = RMSNorm(head_dim, eps=1e-6)
-        if added_kv:
-            self.add_q_proj = nn.Linear(dim, inner, bias=True)
-            self.add_k_proj = nn.Linear(dim, inner, bias=True)
-            self.add_v_proj = nn.Linear(dim, inner, bias=True)
-            self.norm_added_q = RMSNorm(head_dim, eps=1e-6)
-            self.norm_added_k = RMSNorm(head_dim, eps=1e-6)
-            self.to_add_out = nn.Linear(inner, dim, bias=True)
-        if not pre_only:
-            self.to_out = nn.ModuleList([nn.Linear(inner, dim, bias=True), nn.Dropout(0.0)])
-        self.processor = processor
-
-    def set_processor(self, processor):
-        self.processor = processor
-
-    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
-        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
-                              attention_mask=attention_mask, **kw)
-
-
-class FluxTransformerBlock(nn.Module):
-    """[EXT] diffusers FluxTransformerBlock (double stream)."""
-
-    def __init__(self, dim, heads, head_dim):
-        super().__init__()
-        self.norm1 = AdaLayerNormZero(dim)
-        self.norm1_context = AdaLayerNormZero(dim)
-        self.attn = Attention(dim, heads, head_dim, added_kv=True)
-        self.norm2 = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
-        self.ff = FeedForward(dim)
-        self.norm2_context = nn.LayerNorm(dim, elementwise_affine=False, eps=1e-6)
-        self.ff_context = FeedForward(dim)
-
-    def forward(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb=None, joint_attention_kwargs=None):
-        norm_h, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, emb=temb)
-        norm_c, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(encoder_hidden_states, emb=temb)
-        attn_output, context_attn_output = self.attn(
-            hidden_states=norm_h, encoder_hidden_states=norm_c, image_rotary_emb=image_rotary_emb,
-            **(joint_attention_kwargs or {}))
-        attn_output = gate_msa.unsqueeze(1) * attn_output
-        hidden_states = hidden_states + attn_output
-        norm_h = self.norm2(hidden_states)
-        norm_h = norm_h * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
-        ff_output = self.ff(norm_h)
-        ff_output = gate_mlp.unsqueeze(1) * ff_output
-        hidden_states = hidden_states + ff_output
-        context_attn_output = c_gate_msa.unsqueeze(1) * context_attn_output
-        encoder_hidden_states = encoder_hidden_states + context_attn_output
-        norm_c = self.norm2_context(encoder_hidden_states)
-        norm_c = norm_c * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
-        context_ff_output = self.ff_context(norm_c)
-        encoder_hidden_states = encoder_hidden_states + c_gate_mlp.unsqueeze(1) * context_ff_output
-        return encoder_hidden_states, hidden_states
-
-
-class FluxSingleTransformerBlock(nn.Module):
-    """[EXT] diffusers FluxSingleTransformerBlock (takes the two streams, concatenates inside)."""
-
-    def __init__(self, dim, heads, head_dim, mlp_ratio=4.0):
-        super().__init__()
-        self.mlp_hidden_dim = int(dim * mlp_ratio)
-        self.norm = AdaLayerNormZeroSingle(dim)
-        self.proj_mlp = nn.Linear(dim, self.mlp_hidden_dim)
-        self.proj_out = nn.Linear(dim + self.mlp_hidden_dim, dim)
-        self.attn = Attention(dim, heads, head_dim, added_kv=False, pre_only=True)
-
-    def forward(self, hidden_states, encoder_hidden_states, temb, image_rotary_emb=None, joint_attention_kwargs=None):
-        text_seq_len = encoder_hidden_states.shape[1]
-        hidden_states = torch.cat([encoder_hidden_states, hidden_states], dim=1)
-        residual = hidden_states
-        norm_h, gate = self.norm(hidden_states, emb=temb)
-        mlp_h = F.gelu(self.proj_mlp(norm_h), approximate="tanh")
-        attn_output = self.attn(hidden_states=norm_h, image_rotary_emb=image_rotary_emb, **(joint_attention_kwargs or {}))
-        hidden_states = torch.cat([attn_output, mlp_h], dim=2)
-        hidden_states = gate.unsqueeze(1) * self.proj_out(hidden_states)
-        hidden_states = residual + hidden_states
-        return hidden_states[:, :text_seq_len], hidden_states[:, text_seq_len:]
-
-
-def get_timestep_embedding(timesteps, embedding_dim=256, max_period=10000, scale=1.0):
-    """[EXT] flip_sin_to_cos=True, downscale_freq_shift=0; `scale` multiplies the ANGLES (diffusers: emb = scale * emb)."""
-    half = embedding_dim // 2
-    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32)
-    exponent = exponent / half
-    emb = torch.exp(exponent)
-    emb = timesteps[:, None].float() * emb[None, :]
-    if scale != 1.0:
-        emb = scale * emb
-    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
-    return torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
-
-
-class _MLPEmbed(nn.Module):
-    def __init__(self, d_in, d):
-        super().__init__()
-        self.linear_1 = nn.Linear(d_in, d)
-        self.linear_2 = nn.Linear(d, d)
-
-    def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
-
-
-class CombinedTimestepGuidanceTextProjEmbeddings(nn.Module):
-    """[EXT] FLUX time_text_embed (guidance_embeds=True)."""
-
-    def __init__(self, d, pooled_dim):
-        super().__init__()
-        self.timestep_embedder = _MLPEmbed(256, d)
-        self.guidance_embedder = _MLPEmbed(256, d)
-        self.text_embedder = _MLPEmbed(pooled_dim, d)
-
-    def forward(self, timestep, guidance, pooled_projection):
-        t = self.timestep_embedder(get_timestep_embedding(timestep).to(pooled_projection.dtype))
-        g = self.guidance_embedder(get_timestep_embedding(guidance).to(pooled_projection.dtype))
-        return t + g + self.text_embedder(pooled_projection)
-
-
-class _Cfg(dict):
-    __getattr__ = dict.__getitem__
-
-
-class FluxTransformer2DModel(nn.Module):
-    """[EXT] module tree of diffusers FluxTransformer2DModel; forward is replaced by the reference."""
-
-    def __init__(self, in_channels=64, n_double=2, n_single=2, heads=2, head_dim=128, joint_dim=256,
-                 pooled_dim=64, axes_dim=(16, 56, 56)):
-        super().__init__()
-        d = heads * head_dim
-        self.config = _Cfg(in_channels=in_channels, guidance_embeds=True)
-        self.gradient_checkpointing = False
-        self.pos_embed = FluxPosEmbed(theta=10000, axes_dim=axes_dim)
-        self.time_text_embed = CombinedTimestepGuidanceTextProjEmbeddings(d, pooled_dim)
-        self.context_embedder = nn.Linear(joint_dim, d)
-        self.x_embedder = nn.Linear(in_channels, d)
-        self.transformer_blocks = nn.ModuleList([FluxTransformerBlock(d, heads, head_dim) for _ in range(n_double)])
-        self.single_transformer_blocks = nn.ModuleList(
-            [FluxSingleTransformerBlock(d, heads, head_dim) for _ in range(n_single)])
-        self.norm_out = AdaLayerNormContinuous(d, d)
-        self.proj_out = nn.Linear(d, in_channels, bias=True)
-
-    def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
-        raise RuntimeError("vanilla forward not restated; reference rebinding expected")
-
-
-# ----- Step1X-Edit [EXT] stubs (FLUX trunk; diffusers-fork transformer_step1x_edit.py semantics, restated) -----
-class Step1XEditTransformer2DModel(nn.Module):
-    """[EXT] module tree the reference's Step1X forwards touch (Step1XEdit/inplace.py:514-522,
-    Step1XEditV1P2/inplace.py:602-621): connector -> (encoder states, pooled y), x_embedder, time_proj / time_embed,
-    vec_embed, context_embedder, pos_embed, FLUX-shaped double / single blocks, norm_out, proj_out.  The real
-    connector is a Qwen2-VL adapter; here it hands through the prompt embeddings and returns the pooled vector that
-    was registered for that prompt (`set_vec`), which is what the engine takes as an input too."""
-
-    def __init__(self, in_channels=64, n_double=2, n_single=2, heads=2, head_dim=128, joint_dim=256,
-                 pooled_dim=64, axes_dim=(16, 56, 56)):
-        super().__init__()
-        d = heads * head_dim
-        self.config = _Cfg(in_channels=in_channels, guidance_embeds=False)
-        self.gradient_checkpointing = False
-        self.text_token_mapping = None
-        self.pos_embed = FluxPosEmbed(theta=10000, axes_dim=axes_dim)
-        self.time_embed = _MLPEmbed(256, d)
-        self.vec_embed = _MLPEmbed(pooled_dim, d)
-        self.context_embedder = nn.Linear(joint_dim, d)
-        self.x_embedder = nn.Linear(in_channels, d)
-        self.transformer_blocks = nn.ModuleList([FluxTransformerBlock(d, heads, head_dim) for _ in range(n_double)])
-        self.single_transformer_blocks = nn.ModuleList(
-            [FluxSingleTransformerBlock(d, heads, head_dim) for _ in range(n_single)])
-        for b in list(self.transformer_blocks) + list(self.single_transformer_blocks):
-            b.attn.added_kv_proj_dim = d if hasattr(b.attn, "add_q_proj") else None
-        self.norm_out = AdaLayerNormContinuous(d, d)
-        self.proj_out = nn.Linear(d, in_channels, bias=True)
-        self._vec = {}
-
-    def set_vec(self, prompt_embeds, y):
-        self._vec[float(prompt_embeds.float().sum())] = y
-
-    def time_proj(self, timestep):
-        return get_timestep_embedding(timestep, 256)
-
-    def connector(self, encoder_hidden_states, timestep, mask):
-        ys = [self._vec[float(encoder_hidden_states[b:b + 1].float().sum())] for b in range(encoder_hidden_states.shape[0])]
-        return encoder_hidden_states, torch.cat(ys, 0)
-
-    def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
-        raise RuntimeError("vanilla forward not restated; reference rebinding expected")
-
-
-# ----- Qwen-Image [EXT] stubs (diffusers transformer_qwenimage.py semantics, restated) -----------------
-class QwenImageTransformerBlock(FluxTransformerBlock):
-    """[EXT] QwenImageTransformerBlock: img_mod / txt_mod = SiLU + Linear(d, 6d) chunked (shift1, scale1, gate1,
-    shift2, scale2, gate2), LayerNorm(no affine, eps 1e-6), joint attention, FeedForward(gelu-approximate) -
-    the same dataflow and parameter shapes as the FLUX double block, so the FLUX stub is reused under the FLUX
-    parameter names (norm1 = img_mod, norm1_context = txt_mod, ff = img_mlp, ff_context = txt_mlp)."""
-
-    def forward(self, hidden_states, encoder_hidden_states, encoder_hidden_states_mask=None, temb=None,
-                image_rotary_emb=None, joint_attention_kwargs=None):
-        kw = joint_attention_kwargs or {}
-        norm_h, gate_msa, shift_mlp, scale_mlp, gate_mlp = self.norm1(hidden_states, emb=temb)
-        norm_c, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = self.norm1_context(encoder_hidden_states, emb=temb)
-        attn_output, context_attn_output = self.attn(
-            hidden_states=norm_h, encoder_hidden_states=norm_c, encoder_hidden_states_mask=encoder_hidden_states_mask,
-            image_rotary_emb=image_rotary_emb, **kw)
-        hidden_states = hidden_states + gate_msa.unsqueeze(1) * attn_output
-        encoder_hidden_states = encoder_hidden_states + c_gate_msa.unsqueeze(1) * context_attn_output
-        norm_h = self.norm2(hidden_states) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
-        hidden_states = hidden_states + gate_mlp.unsqueeze(1) * self.ff(norm_h)
-        norm_c = self.norm2_context(encoder_hidden_states) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
-        encoder_hidden_states = encoder_hidden_states + c_gate_mlp.unsqueeze(1) * self.ff_context(norm_c)
-        return encoder_hidden_states, hidden_states
-
-
-class QwenTimestepProjEmbeddings(nn.Module):
-    """[EXT] Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0, scale=1000) + TimestepEmbedding."""
-
-    def __init__(self, d):
-        super().__init__()
-        self.timestep_embedder = _MLPEmbed(256, d)
-
-    def forward(self, timestep, hidden_states):
-        proj = get_timestep_embedding(timestep, 256, scale=1000.0)       # Timesteps(..., scale=1000) on timestep / 1000
-        return self.timestep_embedder(proj.to(hidden_states.dtype))
-
-
-class QwenEmbedRope(nn.Module):
-    """[EXT] QwenEmbedRope(theta, axes_dim, scale_rope=True): complex tables (vid_freqs [sum f*h*w, 64], txt_freqs [T, 64])."""
-
-    def __init__(self, theta=10000, axes_dim=(16, 56, 56)):
-        super().__init__()
-        self.theta, self.axes_dim = theta, axes_dim
-        pos_index, neg_index = torch.arange(4096), torch.arange(4096).flip(0) * -1 - 1
-        self.pos_freqs = torch.cat([self._params(pos_index, d) for d in axes_dim], dim=1)
-        self.neg_freqs = torch.cat([self._params(neg_index, d) for d in axes_dim], dim=1)
-
-    def _params(self, index, dim):
-        freqs = torch.outer(index.float(), 1.0 / torch.pow(self.theta, torch.arange(0, dim, 2).to(torch.float32).div(dim)))
-        return torch.polar(torch.ones_like(freqs), freqs)
-
-    def forward(self, video_fhw, txt_seq_lens, device=None):
-        if isinstance(video_fhw, list) and isinstance(video_fhw[0], (list, tuple)) and isinstance(video_fhw[0][0], (list, tuple)):
-            video_fhw = video_fhw[0]
-        vid, max_vid = [], 0
-        half = [x // 2 for x in self.axes_dim]
-        for idx, (frame, height, width) in enumerate(video_fhw):
-            fp = self.pos_freqs.split(half, dim=1)
-            fn = self.neg_freqs.split(half, dim=1)
-            f = fp[0][idx: idx + frame].view(frame, 1, 1, -1).expand(frame, height, width, -1)
-            hh = torch.cat([fn[1][-(height - height // 2):], fp[1][: height // 2]], 0).view(1, height, 1, -1).expand(frame, height, width, -1)
-            ww = torch.cat([fn[2][-(width - width // 2):], fp[2][: width // 2]], 0).view(1, 1, width, -1).expand(frame, height, width, -1)
-            vid.append(torch.cat([f, hh, ww], dim=-1).reshape(frame * height * width, -1))
-            max_vid = max(max_vid, height // 2, width // 2)
-        max_len = int(max(txt_seq_lens))
-        return torch.cat(vid, 0), self.pos_freqs[max_vid: max_vid + max_len]
-
-
-class QwenImageTransformer2DModel(nn.Module):
-    """[EXT] module tree of diffusers QwenImageTransformer2DModel; forward is replaced by the reference."""
-
-    def __init__(self, in_channels=64, n_double=3, heads=2, head_dim=128, joint_dim=256, axes_dim=(16, 56, 56)):
-        super().__init__()
-        d = heads * head_dim
-        self.config = _Cfg(in_channels=in_channels, guidance_embeds=False)
-        self.gradient_checkpointing = False
-        self.pos_embed = QwenEmbedRope(theta=10000, axes_dim=axes_dim)
-        self.time_text_embed = QwenTimestepProjEmbeddings(d)
-        self.txt_norm = RMSNorm(joint_dim, eps=1e-6)
-        self.img_in = nn.Linear(in_channels, d)
-        self.txt_in = nn.Linear(joint_dim, d)
-        self.transformer_blocks = nn.ModuleList([QwenImageTransformerBlock(d, heads, head_dim) for _ in range(n_double)])
-        self.norm_out = AdaLayerNormContinuous(d, d)
-        self.proj_out = nn.Linear(d, in_channels, bias=True)
-
-    def cache_context(self, name):
-        from contextlib import nullcontext
-        return nullcontext()
-
-    def forward(self, *a, **k):  # pragma: no cover - always rebound by warp_modules
-        raise RuntimeError("vanilla forward not restated; reference rebinding expected")
+import os as _os
+
+sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tests"))
+# the [EXT] module trees live in tests/host_trunks.py (shipped with the tests: the host stand-ins use them too); this file
+# is the import harness around them and stays in the build container
+from host_trunks import (  # noqa: E402,F401
+    AdaLayerNormContinuous,
+    AdaLayerNormZero,
+    AdaLayerNormZeroSingle,
+    Attention,
+    CombinedTimestepGuidanceTextProjEmbeddings,
+    FeedForward,
+    FluxPosEmbed,
+    FluxSingleTransformerBlock,
+    FluxTransformer2DModel,
+    FluxTransformerBlock,
+    QwenEmbedRope,
+    QwenImageTransformer2DModel,
+    QwenImageTransformerBlock,
+    QwenTimestepProjEmbeddings,
+    RMSNorm,
+    Step1XEditTransformer2DModel,
+    _Cfg,
+    _GELUProj,
+    _MLPEmbed,
+    apply_rotary_emb,
+    get_1d_rotary_pos_embed,
+    get_timestep_embedding,
+)
 
 
 class FluxAttnProcessor:  # placeholder so unwarp_modules can construct one
