@@ -70,7 +70,22 @@ class KernelTimer:
         import regione_amd.ops as ops
         self._orig_gemm, self._orig_attn, self._orig_pair = ops.gemm, ops.attention, ops.gemm_pair
         self._orig_qkv, self._orig_qkv_pair = ops.gemm_qkv, ops.gemm_qkv_pair
+        self._orig_group = ops.gemm_group
         timer = self
+
+        def gemm_group(problems, **kw):              # batched CFG branches: up to four problems, one launch
+            ps = [p for p in problems if p.A.shape[0] > 0]
+            if not ps:
+                return None
+            N, K = ps[0].W.shape
+            ms = [p.A.shape[0] for p in ps]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = timer._orig_group(problems, **kw)
+            e.record()
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * sum(ms) * N * K))
+            timer.shapes.setdefault((sum(ms[0::2]), sum(ms[1::2]), N, K), []).append((s, e))
+            return r
 
         def timed_gemm(fn, m0, m1, N, K, *a, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -121,11 +136,13 @@ class KernelTimer:
 
         ops.gemm, ops.attention, ops.gemm_pair = gemm, attention, gemm_pair
         ops.gemm_qkv, ops.gemm_qkv_pair = gemm_qkv, gemm_qkv_pair
+        ops.gemm_group = gemm_group
 
     def unwrap(self):
         import regione_amd.ops as ops
         ops.gemm, ops.attention, ops.gemm_pair = self._orig_gemm, self._orig_attn, self._orig_pair
         ops.gemm_qkv, ops.gemm_qkv_pair = self._orig_qkv, self._orig_qkv_pair
+        ops.gemm_group = self._orig_group
 
     def summary(self):
         out = {}

@@ -158,7 +158,8 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                         MANAGER, (full_step, prompt_embeds.shape[1], negative_prompt_embeds.shape[1]), not full_step)
                     noise_pred, neg = D.run_cfg_branches(None, lambda: branch(prompt_embeds, pooled_prompt_embeds, "cond"),
                                                          lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, "uncond"),
-                                                         concurrent=conc)
+                                                         concurrent=conc,
+                                                         batch_on=None if getattr(MANAGER, "strict_reference", False) else self.transformer)
                     noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
                 else:
                     noise_pred = branch(prompt_embeds, pooled_prompt_embeds, "cond")

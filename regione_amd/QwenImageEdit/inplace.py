@@ -117,7 +117,8 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
                                                  not full_step)
                     noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                                          lambda: branch(prompt_embeds, "cond"),
-                                                         lambda: branch(negative_prompt_embeds, "uncond"), concurrent=conc)
+                                                         lambda: branch(negative_prompt_embeds, "uncond"), concurrent=conc,
+                                                         batch_on=tr)
                     noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
                 else:
                     noise_pred = branch(prompt_embeds, "cond")

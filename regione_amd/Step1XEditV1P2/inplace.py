@@ -110,7 +110,8 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
                                              not full_step)
                 pos, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                               lambda: branch(prompt_embeds, text_ids, "cond"),
-                                              lambda: branch(negative_prompt_embeds, neg_text_ids, "uncond"), concurrent=conc)
+                                              lambda: branch(negative_prompt_embeds, neg_text_ids, "uncond"), concurrent=conc,
+                                              batch_on=tr)
                 mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN                    # :421
                 noise_pred = TO.R.cfg_combine(pos, neg, true_cfg_scale, mode, process_norm_power)
                 cache = noise_pred

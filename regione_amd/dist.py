@@ -171,8 +171,15 @@ def branches_concurrent(owner, key, region_step: bool) -> bool:
     return False
 
 
+def branch_batching() -> bool:
+    """RGN_BATCH_BRANCHES (default 1): the two CFG forwards of a computed step run as ONE batched pass through the trunk (the
+    reference's B = 2 forward, Step1XEdit/inplace.py:381-399); 0 = two forwards (in sequence or on two streams)."""
+    import os
+    return os.environ.get("RGN_BATCH_BRANCHES", "1") != "0"
+
+
 def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch.Tensor], run_uncond: Callable[[], torch.Tensor],
-                     concurrent: bool = False):
+                     concurrent: bool = False, batch_on=None):
     """Both CFG forwards of one computed step: without a pair sequentially in the reference's order (cond, then uncond) - or,
     with `concurrent` (the caller says the two forwards touch disjoint state: per-branch K/V caches, tables already built),
     the uncond forward on a SIDE STREAM forked from the caller's stream and joined before the combine: the same launches
@@ -182,6 +189,17 @@ def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch
     rank + exchange."""
     if pair is not None:
         return pair.exchange(run_cond() if pair.role == "cond" else run_uncond())
+    if batch_on is not None and branch_batching() and hasattr(batch_on, "begin_batch"):
+        # `batch_on` = the transformer both closures call: it records the two forwards and executes them as one batched pass
+        # (per-branch K/V caches, rotary tables and AdaLN vectors; weights streamed once, one launch per Linear)
+        batch_on.begin_batch()
+        try:
+            pos, neg = run_cond(), run_uncond()
+        except BaseException:
+            batch_on.abort_batch()
+            raise
+        outs = batch_on.end_batch()
+        return pos.resolve(outs), neg.resolve(outs)
     if not (concurrent and torch.cuda.is_available()):
         pos = run_cond()
         return pos, run_uncond()

@@ -37,6 +37,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
+from .. import dist as D
 from .. import ops
 from .. import torch_ops as TO          # TO.R = torch.ops.regione_mi: the dispatcher-visible op surface
 from ..synth import FluxConfig
@@ -207,7 +208,9 @@ class Workspace:
         self.rows = 0
         self.skv_pad = 0
 
-    def ensure(self, rows: int, skv: int):
+    def ensure(self, rows: int, skv: int, branches: int = 1):
+        """`rows` activation rows in total; one plain-phase K / V^T scratch slab of `skv` rows per CFG branch of a batched
+        forward (both branches' projections run in ONE launch before either attention)."""
         d, ff = self.cfg.d, self.cfg.d * self.cfg.mlp_ratio
         if rows > self.rows:
             kw = dict(dtype=torch.bfloat16, device=self.device)
@@ -216,11 +219,25 @@ class Workspace:
             self.wide = torch.empty(rows, 3 * d + ff, **kw)        # [k | v | q | mlp]
             self.rows = rows
         pad = ops.padded(skv)
-        if pad > self.skv_pad:
+        if pad > self.skv_pad or branches > len(getattr(self, "k_scratch_b", ())):
             kw = dict(dtype=torch.bfloat16, device=self.device)
-            self.k_scratch = torch.zeros(pad, d, **kw)            # zero-filled: pad rows must stay finite
-            self.vt_scratch = torch.zeros(d, pad, **kw)
+            pad = max(pad, self.skv_pad)
+            n = max(branches, len(getattr(self, "k_scratch_b", ())))
+            self.k_scratch_b = [torch.zeros(pad, d, **kw) for _ in range(n)]   # zero-filled: pad rows must stay finite
+            self.vt_scratch_b = [torch.zeros(d, pad, **kw) for _ in range(n)]
+            self.k_scratch, self.vt_scratch = self.k_scratch_b[0], self.vt_scratch_b[0]
             self.skv_pad = pad
+
+
+class WsView:
+    """The rows of ONE CFG branch inside the shared activation buffers of a batched forward: branch b's [text ; image] rows
+    start at `base`; it owns scratch slab b.  Duck-types Workspace for the single-branch block / processor code."""
+
+    def __init__(self, ws: Workspace, base: int, bi: int):
+        self.ws, self.base, self.bi = ws, base, bi
+        self.cfg, self.device = ws.cfg, ws.device
+        self.x, self.nrm, self.wide = ws.x[base:], ws.nrm[base:], ws.wide[base:]
+        self.k_scratch, self.vt_scratch = ws.k_scratch_b[bi], ws.vt_scratch_b[bi]
 
 
 class Modulation:
@@ -360,6 +377,54 @@ class FluxAttnProcessor:
         return wide[:, 2 * d:]                                       # cat([attn_output, mlp_hidden], dim=2)
 
 
+    # -- batched CFG branches: ONE projection launch for every branch (and stream), attention per branch -----------------
+    def multi(self, attn: Attention, block, ctxs: List["FwdCtx"], ropes):
+        """The attention half of a block for several CFG branches at once (reference: the B = 2 forward of
+        Step1XEdit/inplace.py:381-399; rows of different branches never meet in a Linear).  Per branch: its own K / V^T
+        destination (`kv_target`: scratch slab, store, or partial update of ITS cache), rotary tables and cache-row list in
+        the fused Q/K/V epilogue; the weights are streamed once.  Results per row are what the single-branch path computes."""
+        d, H = attn.heads * attn.head_dim, attn.heads
+        xs, ws_, bs, outs, nq, nk, cq, sq, ck, sk, rows, kc, vc, rb, rt = ([] for _ in range(15))
+        per = []
+        for ctx, rope_q in zip(ctxs, ropes):
+            wsv, T, M = ctx.ws, ctx.T, ctx.M
+            R = T + M
+            k_slab, vt_slab, kv_rows, skv, rope_k = self.kv_target(attn, ctx)
+            rope_k = rope_k if rope_k is not None else rope_q
+            partial = kv_rows is not None
+            ctx.partial_kv = partial
+            per.append((wsv, T, R, k_slab, vt_slab, skv))
+            if self.single:
+                probs = ((wsv.nrm[:R], attn.w_kvqm, attn.b_kvqm, wsv.wide[:R], attn.norm_q, attn.norm_k, 0, partial),)
+            else:           # image rows sit behind the T text rows of the branch's joint sequence; only they are ever partial
+                probs = ((wsv.nrm[T:R], attn.w_kvq, attn.b_kvq, wsv.wide[T:R, :3 * d], attn.norm_q, attn.norm_k, T, partial),
+                         (wsv.nrm[:T], attn.w_add_kvq, attn.b_add_kvq, wsv.wide[:T, :3 * d], attn.norm_added_q,
+                          attn.norm_added_k, 0, False))
+            for x, w, b, o, wq, wk, row_base, rtrip in probs:
+                xs.append(x); ws_.append(w); bs.append(b); outs.append(o); nq.append(wq); nk.append(wk)
+                cq.append(rope_q[0]); sq.append(rope_q[1]); ck.append(rope_k[0]); sk.append(rope_k[1])
+                rows.append(kv_rows); kc.append(k_slab); vc.append(vt_slab); rb.append(row_base); rt.append(rtrip)
+        TO.R.kv_partial_update_group_(xs, ws_, bs, outs, nq, nk, cq, sq, ck, sk, rows, kc, vc, H, rb, 1e-6, rt,
+                                      3 * d if self.single else -1)
+        for wsv, T, R, k_slab, vt_slab, skv in per:
+            q = wsv.wide[:R, 2 * d:3 * d]
+            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
+        if self.single:
+            return
+        group = []
+        for ctx, (wsv, T, R, _, _, _) in zip(ctxs, per):
+            g_img, g_txt = block.gates_msa(ctx)
+            q = wsv.wide[:R, 2 * d:3 * d]
+            group.append(ops.Problem(q[T:R], attn.w_out, attn.b_out, wsv.x[T:R], gate=g_img, resid=wsv.x[T:R]))
+            group.append(ops.Problem(q[:T], attn.w_add_out, attn.b_add_out, wsv.x[:T], gate=g_txt, resid=wsv.x[:T]))
+        ops.gemm_group(group, epilogue=ops.EPI_GATE_RESID)
+
+
+def _branch_rows(ctxs) -> int:
+    last = ctxs[-1]
+    return last.ws.base + last.T + last.M
+
+
 class FluxTransformerBlock:
     """[EXT] FluxTransformerBlock (double stream) on the shared workspace."""
 
@@ -402,6 +467,33 @@ class FluxTransformerBlock:
         return ws.x[:T], ws.x[T:R]
 
 
+    def multi(self, ctxs: List[FwdCtx], ropes):
+        """The block for several CFG branches laid out [text_0 ; image_0 ; text_1 ; image_1] in one activation buffer: one
+        LN-modulate launch (a row segment per stream and branch, per-branch AdaLN vectors), one launch per projection."""
+        ws = ctxs[0].ws.ws
+        Rtot, d = _branch_rows(ctxs), ws.cfg.d
+
+        def segs(i_shift, i_scale):
+            out = []
+            for c in ctxs:
+                b = c.ws.base
+                out.append((b + c.T, c.mods.chunk(self.mo_ctx, i_shift), c.mods.chunk(self.mo_ctx, i_scale)))
+                out.append((b + c.T + c.M, c.mods.chunk(self.mo_img, i_shift), c.mods.chunk(self.mo_img, i_scale)))
+            return out
+        ops.ln_modulate_segs(ws.x[:Rtot], ws.nrm[:Rtot], segs(0, 1))
+        self.attn.processor.multi(self.attn, self, ctxs, ropes)
+        ops.ln_modulate_segs(ws.x[:Rtot], ws.nrm[:Rtot], segs(3, 4))
+        up, down = [], []
+        for c in ctxs:
+            v, T, R = c.ws, c.T, c.T + c.M
+            ffh = v.wide[:R, 3 * d:]
+            up += [ops.Problem(v.nrm[T:R], self.ff_w1, self.ff_b1, ffh[T:R]), ops.Problem(v.nrm[:T], self.ffc_w1, self.ffc_b1, ffh[:T])]
+            down += [ops.Problem(ffh[T:R], self.ff_w2, self.ff_b2, v.x[T:R], gate=c.mods.chunk(self.mo_img, 5), resid=v.x[T:R]),
+                     ops.Problem(ffh[:T], self.ffc_w2, self.ffc_b2, v.x[:T], gate=c.mods.chunk(self.mo_ctx, 5), resid=v.x[:T])]
+        ops.gemm_group(up, epilogue=ops.EPI_GELU)
+        ops.gemm_group(down, epilogue=ops.EPI_GATE_RESID)
+
+
 class FluxSingleTransformerBlock:
     """[EXT] FluxSingleTransformerBlock on the shared workspace."""
 
@@ -421,6 +513,18 @@ class FluxSingleTransformerBlock:
         rows = ws.x[:R] if cat.shape[0] == R else ws.x[T:T + cat.shape[0]]      # last block: only the rows the caller reads
         ops.gemm(cat, self.w_po, self.b_po, rows, epilogue=ops.EPI_GATE_RESID, gate=mods.chunk(self.mo, 2), resid=rows)
         return ws.x[:T], ws.x[T:R]
+
+
+    def multi(self, ctxs: List[FwdCtx], ropes):
+        ws = ctxs[0].ws.ws
+        Rtot = _branch_rows(ctxs)
+        ops.ln_modulate_segs(ws.x[:Rtot], ws.nrm[:Rtot],
+                             [(c.ws.base + c.T + c.M, c.mods.chunk(self.mo, 0), c.mods.chunk(self.mo, 1)) for c in ctxs])
+        self.attn.processor.multi(self.attn, self, ctxs, ropes)
+        d = ws.cfg.d
+        ops.gemm_group([ops.Problem(c.ws.wide[:c.T + c.M, 2 * d:], self.w_po, self.b_po, c.ws.x[:c.T + c.M],
+                                    gate=c.mods.chunk(self.mo, 2), resid=c.ws.x[:c.T + c.M]) for c in ctxs],
+                       epilogue=ops.EPI_GATE_RESID)
 
 
 class FluxTransformer2DModel:
@@ -655,6 +759,27 @@ class FluxTransformer2DModel:
 
     MAX_SIDE_LANES = 2
 
+    # -- batched CFG branches -----------------------------------------------------------------------------------------
+    # The reference runs classifier-free guidance either as ONE forward on a batch of two (Step1XEdit/inplace.py:381-399) or
+    # as two forwards in sequence (Step1XEditV1P2/inplace.py:398,416; QwenImageEdit/inplace.py:371-405; FLUX true CFG,
+    # FluxKontext/inplace.py:349-364).  Rows of different branches never interact inside the trunk, so the engine can run
+    # both through one set of launches: between `begin_batch()` and `end_batch()` every forward call only RECORDS its
+    # arguments (the family's forward has already resolved rotary tables, connector outputs, tags) and returns a handle;
+    # `end_batch()` executes all recorded branches as one batched pass and returns their outputs in call order.
+    def begin_batch(self):
+        self._batch = []
+
+    def abort_batch(self):
+        self._batch = None
+
+    def end_batch(self) -> List[torch.Tensor]:
+        recs, self._batch = self._batch, None
+        if not recs:
+            return []
+        if len(recs) == 1:
+            return [self._run(*recs[0]["args"], out_rows=recs[0]["out_rows"])[0]]
+        return self._run_multi(recs)
+
     def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict,
              joint_attention_kwargs=None, out_rows=None):
         """Shared body of the vanilla and the RegionE forward (inplace.py:469-576).  `out_rows` (or the one-shot attribute
@@ -663,6 +788,11 @@ class FluxTransformer2DModel:
         assert hidden_states.shape[0] == 1, "harness engine runs one image per forward"
         if out_rows is None:
             out_rows = self.__dict__.pop("out_rows_hint", None)
+        if getattr(self, "_batch", None) is not None:          # recording (begin_batch ... end_batch): executed later, together
+            self._batch.append(dict(args=(hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, False,
+                                          joint_attention_kwargs), out_rows=out_rows))
+            handle = BranchHandle(len(self._batch) - 1)
+            return (handle,) if not return_dict else _Cfg(sample=handle)
         if not SKIP_UNREAD_ROWS or getattr(self, "_fp8", False):
             out_rows = None
         M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
@@ -693,6 +823,84 @@ class FluxTransformer2DModel:
         out = torch.empty(1, Mo, self.cfg_model.in_channels, dtype=torch.bfloat16, device=self.device)
         ops.gemm(ws.nrm[T:Ro], self.proj_out_weight, self.proj_out_bias, out[0])
         return (out,) if not return_dict else _Cfg(sample=out)
+
+
+class BranchHandle:
+    """What a forward call returns while the transformer records a batch: the index of its output in `end_batch()`'s list,
+    plus the indexing the caller applied to it meanwhile (`tr(...)[0][:, :n]`), replayed by `resolve`."""
+
+    def __init__(self, index: int, keys=()):
+        self.index, self.keys = index, tuple(keys)
+
+    def __getitem__(self, key):
+        return BranchHandle(self.index, self.keys + (key,))
+
+    def resolve(self, outs):
+        t = outs[self.index]
+        for k in self.keys:
+            t = t[k]
+        return t
+
+
+def _run_multi(self, recs):
+    """`_run` for several recorded CFG branches (same latent rows, per-branch text, conditioning, rotary tables, cache tag)
+    in ONE pass: activations laid out [text_0 ; image_0 ; text_1 ; image_1 ; ...], every Linear of a block as one launch
+    over all branches (weights streamed once), LayerNorm-modulate with a row segment per stream and branch, attention per
+    branch against that branch's K / V^T.  The LAST block (and norm_out / proj_out) runs per branch on the single-branch code,
+    which knows how to skip the rows nothing reads."""
+    nb = len(recs)
+    assert 2 <= nb <= 2, "batched forwards carry the two CFG branches"
+    d = self.cfg_model.d
+    Ms = [r["args"][0].shape[1] for r in recs]
+    Ts = [r["args"][1].shape[1] for r in recs]
+    assert all(r["args"][0].shape[0] == 1 for r in recs)
+    bases, tot = [], 0
+    for T, M in zip(Ts, Ms):
+        bases.append(tot)
+        tot += T + M
+    ws = self._ws_for_stream()
+    ws.ensure(tot, max(T + M for T, M in zip(Ts, Ms)), nb)
+    views = [WsView(ws, b, i) for i, b in enumerate(bases)]
+    fp8 = getattr(self, "_fp8", False)
+    ctxs, ropes = [], []
+    emb_x, emb_c = [], []
+    for r, v, T, M in zip(recs, views, Ts, Ms):
+        hidden, enc_hs, pooled, timestep, guidance, rope, _, jkw = r["args"]
+        out_rows = r["out_rows"] if (SKIP_UNREAD_ROWS and not fp8) else None
+        Mo = M if out_rows is None else min(int(out_rows), M)
+        emb_x.append(ops.Problem(hidden[0], self.x_embedder_weight, self.x_embedder_bias, v.x[T:T + M]))
+        enc = enc_hs[0]
+        if self.cfg_model.txt_norm:
+            enc = ops.rms_norm_rows(enc, self.txt_norm_weight)
+        emb_c.append(ops.Problem(enc, self.context_embedder_weight, self.context_embedder_bias, v.x[:T]))
+        ts = self._ts_key(timestep)
+        gd = guidance.to(torch.bfloat16) * 1000 if guidance is not None else None
+        mods = self._lookup_modulation(ts, gd, pooled)
+        if mods is None:
+            temb = self.time_text_embed(ts, gd, pooled)
+            mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
+        ctxs.append(FwdCtx(v, T, M, mods, tag=(jkw or {}).get("tag"), out_rows=Mo if (SKIP_UNREAD_ROWS and not fp8) else None))
+        ropes.append(rope)
+    ops.gemm_group(emb_x)
+    ops.gemm_group(emb_c)
+    blocks = list(self.transformer_blocks) + list(self.single_transformer_blocks)
+    for block in blocks[:-1]:
+        block.multi(ctxs, ropes)
+    outs = []
+    for ctx, rope in zip(ctxs, ropes):
+        v, T, M = ctx.ws, ctx.T, ctx.M
+        R = T + M
+        blocks[-1](hidden_states=v.x[T:R], encoder_hidden_states=v.x[:T], temb=ctx, image_rotary_emb=rope)
+        Mo = M if ctx.out_rows is None else ctx.out_rows
+        Ro = T + Mo
+        ops.ln_modulate(v.x[T:Ro], v.nrm[T:Ro], ctx.mods.chunk(self.mo_out, 1), ctx.mods.chunk(self.mo_out, 0))
+        out = torch.empty(1, Mo, self.cfg_model.in_channels, dtype=torch.bfloat16, device=self.device)
+        ops.gemm(v.nrm[T:Ro], self.proj_out_weight, self.proj_out_bias, out[0])
+        outs.append(out)
+    return outs
+
+
+FluxTransformer2DModel._run_multi = _run_multi
 
 
 # ---------------------------------------------------------------------------------------------
@@ -784,19 +992,18 @@ class FluxKontextPipeline:
         for i, t in enumerate(timesteps):
             x = torch.cat([latents, image_latents], dim=1)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
-            self.transformer.out_rows_hint = latents.size(1)
-            noise_pred = self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance,
-                                          pooled_projections=pooled_prompt_embeds,
-                                          encoder_hidden_states=prompt_embeds, txt_ids=text_ids, img_ids=latent_ids,
-                                          return_dict=False)[0]
-            noise_pred = noise_pred[:, : latents.size(1)]
-            if do_true_cfg:
+            def branch(embeds, pooled_e):
                 self.transformer.out_rows_hint = latents.size(1)
-                neg = self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance,
-                                       pooled_projections=negative_pooled_prompt_embeds,
-                                       encoder_hidden_states=negative_prompt_embeds, txt_ids=text_ids,
-                                       img_ids=latent_ids, return_dict=False)[0][:, : latents.size(1)]
+                return self.transformer(hidden_states=x, timestep=timestep / 1000, guidance=guidance, pooled_projections=pooled_e,
+                                        encoder_hidden_states=embeds, txt_ids=text_ids, img_ids=latent_ids,
+                                        return_dict=False)[0][:, : latents.size(1)]
+            if do_true_cfg:
+                noise_pred, neg = D.run_cfg_branches(None, lambda: branch(prompt_embeds, pooled_prompt_embeds),
+                                                     lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds),
+                                                     batch_on=self.transformer)
                 noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_PLAIN)
+            else:
+                noise_pred = branch(prompt_embeds, pooled_prompt_embeds)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
                                                     prompt_embeds)

@@ -149,7 +149,7 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
             if do_true_cfg:
                 noise_pred, neg = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                                      lambda: branch(prompt_embeds, "cond"),
-                                                     lambda: branch(negative_prompt_embeds, "uncond"))
+                                                     lambda: branch(negative_prompt_embeds, "uncond"), batch_on=tr)
                 noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
             else:
                 noise_pred = branch(prompt_embeds, "cond")

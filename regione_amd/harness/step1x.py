@@ -58,12 +58,26 @@ class Step1XEditTransformer2DModel(H.FluxTransformer2DModel):
     def _run_batched(self, hidden_states, encoder_hidden_states, prompt_embeds_mask, timestep, image_rotary_emb,
                      return_dict):
         enc, y = self.connector(encoder_hidden_states, timestep, prompt_embeds_mask)
-        outs = []
         out_rows = self.__dict__.pop("out_rows_hint", None)
-        for b in range(hidden_states.shape[0]):
-            tag = "cond" if b == 0 else "uncond"
-            outs.append(self._run(hidden_states[b:b + 1], enc[b:b + 1], y[b], timestep[b:b + 1], None, image_rotary_emb,
-                                  False, {"tag": tag}, out_rows=out_rows)[0])
+        B = hidden_states.shape[0]
+        # the reference's batch of two (Step1XEdit/inplace.py:381-399) = two recorded branches executed as ONE batched pass
+        # (RGN_BATCH_BRANCHES=0: two passes over the single-image engine, the round-1/2 behaviour)
+        batched = B == 2 and D.branch_batching() and getattr(self, "_batch", None) is None
+        if batched:
+            self.begin_batch()
+        outs = []
+        try:
+            for b in range(B):
+                tag = "cond" if b == 0 else "uncond"
+                outs.append(self._run(hidden_states[b:b + 1], enc[b:b + 1], y[b], timestep[b:b + 1], None, image_rotary_emb,
+                                      False, {"tag": tag}, out_rows=out_rows)[0])
+        except BaseException:
+            if batched:
+                self.abort_batch()
+            raise
+        if batched:
+            res = self.end_batch()
+            outs = [h.resolve(res) for h in outs]
         out = torch.cat(outs, 0)
         return (out,) if not return_dict else H._Cfg(sample=out)
 
@@ -143,7 +157,8 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
                                out_rows=latents.size(1))[0][:, : latents.size(1)]
             outs = D.run_cfg_branches(getattr(self, "_cfg_pair", None),
                                       lambda: branch(prompt_embeds, pooled_prompt_embeds, text_ids, "cond"),
-                                      lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond"))
+                                      lambda: branch(negative_prompt_embeds, negative_pooled_prompt_embeds, neg_text_ids, "uncond"),
+                                      batch_on=tr)
             mode = ops.CFG_STEP1X_RESCALE if float(t) > timesteps_truncate else ops.CFG_PLAIN
             noise_pred = TO.R.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]

@@ -128,6 +128,24 @@ _define("kv_partial_update_pair_",
         "int heads, int txt_len, float eps=1e-6, bool fp16_roundtrip=False) -> ()", _kv_update_pair, lambda *a, **k: None)
 
 
+def _kv_update_group(x, w, b, out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps=1e-6,
+                     fp16_roundtrip=(), gelu_from_col=-1):
+    rt = list(fp16_roundtrip) or [False] * len(x)
+    probs = [ops.Problem(x[i], w[i], b[i], out[i],
+                         epi=_epi(norm_q[i], norm_k[i], cos_q[i], sin_q[i], cos_k[i], sin_k[i], kv_rows[i], k_cache[i], vt_cache[i],
+                                  heads, int(row_base[i]), eps, bool(rt[i]))) for i in range(len(x))]
+    ops.gemm_group(probs, epilogue=3, gelu_from_col=0 if gelu_from_col < 0 else gelu_from_col)
+
+
+# the projections of up to four (stream, CFG branch) problems in ONE launch: per problem its activations, weights (shared
+# between the branches of a stream), RMSNorm weights, rotary tables, cache-row list and K / V^T cache (one per branch)
+_define("kv_partial_update_group_",
+        "(Tensor[] x, Tensor[] w_kvq, Tensor?[] b_kvq, Tensor(a!)[] q_out, Tensor[] norm_q, Tensor[] norm_k, Tensor[] cos_q, "
+        "Tensor[] sin_q, Tensor[] cos_k, Tensor[] sin_k, Tensor?[] kv_rows, Tensor(b!)[] k_cache, Tensor(c!)[] vt_cache, int heads, "
+        "int[] row_base, float eps=1e-6, bool[] fp16_roundtrip=[], int gelu_from_col=-1) -> ()", _kv_update_group,
+        lambda *a, **k: None)
+
+
 def _region_attention(q, k_cache, vt_cache, out, skv, heads, scale=-1.0):
     ops.attention(q, k_cache, vt_cache, out, skv, heads, scale if scale > 0 else None)
 
@@ -151,6 +169,7 @@ class _Direct:
     cfg_combine = staticmethod(ops.cfg_combine)
     kv_partial_update_ = staticmethod(_kv_update)
     kv_partial_update_pair_ = staticmethod(_kv_update_pair)
+    kv_partial_update_group_ = staticmethod(_kv_update_group)
     region_attention = staticmethod(_region_attention)
 
 

@@ -649,6 +649,7 @@ def test_cfg_branches_on_two_streams_bit_identical_to_sequential(golden, mode, m
     split-K / KV-split scratch per stream -> the whole 28-step edit is bit-identical to the sequential run (mode 0), trace
     included, for the tagged-CFG families and for FLUX true CFG."""
     from regione_amd.harness import qwen as HQ
+    monkeypatch.setenv("RGN_BATCH_BRANCHES", "0")            # two forwards per step (the batched pass, round 3, has its own test)
     cfg = synth.FluxConfig(**synth.QWEN_TOY)
     h = w = 16
     wts = synth.make_flux_weights(cfg, seed=6, dtype=torch.bfloat16, w_std=0.05)
@@ -690,3 +691,61 @@ def test_cfg_branches_on_two_streams_bit_identical_to_sequential(golden, mode, m
         outs.append(fpipe(**fkw)[0].clone())
         torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1])
+
+
+
+@pytest.mark.parametrize("family", ["flux_true_cfg", "step1x", "step1x_v1p2", "qwen"])
+def test_cfg_branches_batched_through_one_pass_bit_identical_to_two_forwards(family, golden, monkeypatch):
+    """Round 3: the cond / uncond forwards of a computed step run as ONE batched pass (the reference's B = 2 forward,
+    Step1XEdit/inplace.py:381-399; rows of different branches never meet in a Linear): activations [text_0 ; image_0 ;
+    text_1 ; image_1], one launch per projection over both branches (rgn_gemm_group, per-branch Q/K/V epilogue descriptors,
+    K / V^T caches, rotary tables, AdaLN vectors), attention per branch.  At these dimensions no launch takes a split-K
+    path, so every row sees the same arithmetic as in a forward of its own: the whole 28-step edit - every noise_pred of the
+    trace, the ids, the final latents - is BIT-IDENTICAL to the two-forward run (RGN_BATCH_BRANCHES=0), RegionE on and off."""
+    from regione_amd.harness import qwen as HQ, step1x as HS
+    h = w = 16
+    cu = lambda t: t.cuda() if t is not None else None
+    if family == "qwen":
+        cfg = synth.FluxConfig(**synth.QWEN_TOY)
+        wts = synth.make_flux_weights(cfg, seed=6, dtype=torch.bfloat16, w_std=0.05)
+        pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+        img = golden("qwen_toy_bf16")["image_latents"]
+    elif family == "flux_true_cfg":
+        cfg = synth.FluxConfig(**synth.TOY)
+        wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=0.05)
+        pipe = _toy_pipe(wts, cfg)
+        img = golden("toy_bf16")["image_latents"]
+    else:
+        cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
+        wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+        cls = HS.Step1XEditPipelineV1P2 if family.endswith("v1p2") else HS.Step1XEditPipeline
+        pipe = cls(HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+        img = golden("s1xv2_toy_bf16" if family.endswith("v1p2") else "s1x_toy_bf16")["image_latents"]
+    Tn = 32 if family in ("step1x", "flux_true_cfg") else 24          # v1p1's batch of two and FLUX share the text length
+    lat, _, prompt, y = [cu(t) for t in synth.make_edit_inputs(h, w, 32, cfg, seed=9 if family != "flux_true_cfg" else 42, dtype=torch.bfloat16)]
+    _, _, nprompt, ny = [cu(t) for t in synth.make_edit_inputs(h, w, Tn, cfg, seed=10, dtype=torch.bfloat16)]
+    kw = dict(image=cu(img), prompt_embeds=prompt, negative_prompt_embeds=nprompt, height=h * 16, width=w * 16, latents=lat,
+              true_cfg_scale=4.0, return_dict=False)
+    if family != "qwen":
+        kw.update(pooled_prompt_embeds=y, negative_pooled_prompt_embeds=ny)
+    if family == "flux_true_cfg":
+        kw.update(guidance_scale=2.5)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    monkeypatch.setenv("RGN_BRANCH_STREAMS", "0")
+    res = {}
+    for batched in ("1", "0"):
+        monkeypatch.setenv("RGN_BATCH_BRANCHES", batched)
+        van = pipe(**kw)[0].clone()
+        helper.enable()
+        trace = {}
+        reg = pipe(trace=trace, **kw)[0].clone()
+        torch.cuda.synchronize()
+        res[batched] = (van, reg, pipe._regione_manager.edited_ids.clone(), [x.clone() for x in trace["noise_pred"]], "".join(trace["kind"]))
+        helper.disable()
+    a, b = res["1"], res["0"]
+    assert a[4] == b[4] and "R" in a[4] and "F" in a[4]
+    assert torch.equal(a[2], b[2]) and a[2].numel() > 0
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])), "a noise_pred of the batched pass differs from the two-forward run"
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    assert torch.isfinite(a[1].float()).all()
