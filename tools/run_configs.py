@@ -97,9 +97,9 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
     cfgd = dict(helper.config) if hasattr(helper, "config") else {}
     box = make_box(h_tok, w_tok, frac)
 
-    def edit(trace=None):
+    def edit(trace=None, **extra):
         kw = dict(image=img, prompt_embeds=prompt, height=size, width=size, latents=lat, return_dict=False,
-                  num_inference_steps=steps)
+                  num_inference_steps=steps, **extra)
         if trace is not None:
             kw["trace"] = trace
         if family == "flux":
@@ -141,6 +141,32 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
                full_token_edit_s=tv, full_token_steps_per_s=steps / tv, speedup=tv / tr_s,
                psnr_vs_full_token_db=float(O.psnr(out.cpu(), van.cpu())), cfg_scale=cfg_scale,
                peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, weights="fp8 e4m3fn + per-channel scale" if fp8 else "bf16")
+    # GPU time per denoising step by kind (an event at every callback_on_step_end), and - RGN_CFG_KTIMER=1 - the per-shape
+    # launch table of one more edit (HIP events around every GEMM / attention launch, like bench.py)
+    evs = [torch.cuda.Event(enable_timing=True)]
+    evs[0].record()
+
+    def cb(p, i, t, kw):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
+        return {}
+    tr2 = {}
+    edit(tr2, callback_on_step_end=cb)
+    torch.cuda.synchronize()
+    by = {}
+    for k, m in zip(tr2["kind"], [a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:])]):
+        by.setdefault(k, []).append(m)
+    res["step_ms_by_kind"] = {k: dict(n=len(v), avg_ms=round(sum(v) / len(v), 3), min_ms=round(min(v), 3)) for k, v in by.items()}
+    if os.environ.get("RGN_CFG_KTIMER"):
+        from regione_amd import ops
+        kt = B.KernelTimer()
+        kt.wrap(ops)
+        edit()
+        torch.cuda.synchronize()
+        kt.unwrap()
+        res["kernels"] = {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kt.summary().items()}
+        res["gemm_shapes"] = kt.shape_table(16)
     helper.disable()
     del pipe, helper
     torch.cuda.empty_cache()
