@@ -781,3 +781,63 @@ def test_ln_modulate_four_segments():
     ref = torch.empty_like(out)
     ops.ln_modulate(x.cuda(), ref, mods[1][0].cuda(), mods[1][1].cuda(), split_row=ends[0], shift0=mods[0][0].cuda(), scale0=mods[0][1].cuda())
     assert torch.equal(two, ref)
+
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(4608, 3072, 3072, "gate"), (8704, 21504, 3072, "gelu"), (2048, 704, 15360, "bias"),
+                                       (1536, 3072, 15360, "gate"), (600, 520, 256, "bias"), (9216, 9216, 3072, "bias")])
+def test_gemm_fp8_weights_in_the_hand_scheduled_loop_bit_identical_to_fp8_tile_and_widened_paths(M, N, K, epi, monkeypatch):
+    """Round 3: fp8 (e4m3fn) weight tiles INSIDE the hand-scheduled 4-wave K loop (W ring of three 16 KiB byte slots,
+    ds_read_b64 + in-register v_cvt_scalef32_pk_bf16_fp8 ahead of the MFMAs; the default for 256 x 256 tiles) against the
+    compiler-scheduled fp8-tile kernel (RGN_W8_ASM=0) and the widen-once path of round 2 (RGN_W8_WIDEN_MIN_M=1): the
+    conversion is exact and the MFMA order per output element is the same, so all three agree bit for bit."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = bf(torch.randn(M, K, generator=g)).cuda()
+    Wq = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
+    b = bf(torch.randn(N, generator=g)).cuda()
+    gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
+    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")          # whole-K tiles: the paths' planners may cut remainders differently
+    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")        # 256 x 256 tiles on every path
+    outs = []
+    for asm, widen in (("1", "0"), ("0", "0"), ("0", "1")):
+        monkeypatch.setenv("RGN_W8_ASM", asm)
+        monkeypatch.setenv("RGN_W8_WIDEN_MIN_M", widen)
+        if epi == "gate":
+            o = x.clone()
+            ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
+        else:
+            o = torch.full((M, N), 3.0, dtype=torch.bfloat16, device="cuda")
+            ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GELU if epi == "gelu" else ops.EPI_BIAS, gelu_from_col=N // 2 // 8 * 8)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
+    assert torch.equal(outs[0], outs[2]), float((outs[0].float() - outs[2].float()).abs().max())
+    W = (Wq.float() * Wq._rgn_scale[:, None]).cpu()
+    if epi == "bias":
+        ref = F.linear(A.cpu().float(), W, b.cpu().float())
+        assert rel_err(outs[0].cpu(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("nsplit", [2, 3])
+def test_gemm_fp8_split_k_pieces_in_the_hand_scheduled_loop(nsplit, monkeypatch):
+    """Split-K remainder pieces on fp8 weights run the fp8 asm loop too (pieces of >= 4 K tiles): same result as the
+    compiler-scheduled fp8 pieces at the same piece count."""
+    from regione_amd import ops
+    M, N, K = 1536, 3072, 15360
+    g = torch.Generator().manual_seed(77)
+    A = bf(torch.randn(M, K, generator=g)).cuda()
+    Wq = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
+    b = bf(torch.randn(N, generator=g)).cuda()
+    monkeypatch.setenv("RGN_GEMM_NSPLIT", str(nsplit))
+    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
+    outs = []
+    for asm in ("1", "0"):
+        monkeypatch.setenv("RGN_W8_ASM", asm)
+        o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ops.gemm(A, Wq, b, o)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1])
+    ref = F.linear(A.cpu().float(), (Wq.float() * Wq._rgn_scale[:, None]).cpu(), b.cpu().float())
+    assert rel_err(outs[0].cpu(), ref) < 4e-3

@@ -282,6 +282,135 @@ def emit_v1():
     return lines
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# variant 2: fp8 (OCP e4m3fn) WEIGHTS in the ring variant's loop.  The W tile travels and sits in LDS as BYTES: 256 rows x
+# 64 B = 16 KiB per K tile (half of the bf16 image), 4 DMA pieces per wave instead of 8, a W ring of three 16 KiB slots at
+# 64 K / 80 K / 96 K (two tiles of lead, like variant 1).  A fragment is one `ds_read_b64` (8 fp8 values of one row) into
+# the UPPER two registers of the fragment's four, widened in place by four `v_cvt_scalef32_pk_bf16_fp8` (scale 1.0: exact,
+# every e4m3 value is a bf16 value): f0 <- lo(r0), f1 <- hi(r0), f2 <- lo(r1), f3 <- hi(r1) with (r0, r1) = (f2, f3) - no
+# extra registers.  The MFMAs, their order and the A side are variant 1's, so the accumulators are bit-identical to the
+# compiler-scheduled fp8-tile kernel (gemm_bf16_kernel<.., AV = 8>) and to the widen-once path.
+# Per phase the W raw reads go FIRST (LDS returns in order: `lgkmcnt(8)` = the eight raw reads have landed while the eight A
+# reads may still fly), then one convert per MFMA slot.
+# LDS image of a W slot: piece p (1 KiB) = rows 16p .. 16p+15, lane l -> row l >> 2, 16-byte chunk l & 3 (the source chunk is
+# swizzled ^ ((row >> 2) & 3), the 8-byte fragment slot ^ (((row >> 2) & 3) << 1) - the AV = 8 kernel's image).
+# operands: ob0..ob3 (4 W pieces per wave), kofw advances by 64 bytes per K tile; everything else as variant 1.
+# ------------------------------------------------------------------------------------------------------------------
+W8_SLOT, W8_END = 16384, 65536 + 3 * 16384
+
+
+def raw(set_, f):
+    b = FRAG0 + 64 * set_ + 4 * (8 + f)
+    return f"v[{b + 2}:{b + 3}]"
+
+
+def reads8_w(set_, khalf):
+    return [f"ds_read_b64 {raw(set_, f)}, %{LB(khalf)} offset:{f * 1024}" for f in range(8)]
+
+
+def reads8_a(set_, khalf):
+    return [f"ds_read_b128 {frag(set_, f)}, %{LA(khalf)} offset:{f * 2048}" for f in range(8)]
+
+
+def cvts(set_):
+    out = []
+    for f in range(8):
+        b = FRAG0 + 64 * set_ + 4 * (8 + f)
+        out += [f"v_cvt_scalef32_pk_bf16_fp8 v{b}, v{b + 2}, 1.0",
+                f"v_cvt_scalef32_pk_bf16_fp8 v{b + 1}, v{b + 2}, 1.0 op_sel:[1,0,0]",
+                f"v_cvt_scalef32_pk_bf16_fp8 v{b + 2}, v{b + 3}, 1.0",
+                f"v_cvt_scalef32_pk_bf16_fp8 v{b + 3}, v{b + 3}, 1.0 op_sel:[1,0,0]"]
+    return out
+
+
+def dma_w8():
+    return [(f"s_add_u32 m0, %{WAS}, {q * 1024}", f"buffer_load_dwordx4 %{OB(q)}, %{PW}, %{KOFW} offen lds") for q in range(4)]
+
+
+def adv_w8():
+    return [f"s_add_u32 %{KOFW}, %{KOFW}, 64", f"s_add_u32 %{WAS}, %{WAS}, {W8_SLOT}", f"s_cmp_lt_u32 %{WAS}, {W8_END}",
+            f"s_cselect_b32 %{WAS}, %{WAS}, %[wwrap]"]
+
+
+def rot_wrd8():
+    return [f"s_add_u32 %{WRD}, %{WRD}, {W8_SLOT}", f"s_cmp_lt_u32 %{WRD}, {W8_END}", f"s_cselect_b32 %{WRD}, %{WRD}, {W_SLOT0}"]
+
+
+def prologue2():
+    ins = []
+
+    def issue(pcs):
+        for m0set, ld in pcs:
+            ins.extend([m0set, "s_nop 0", ld])
+    issue(dma_a()); ins.extend(adv_a())          # A(0)
+    issue(dma_w8()); ins.extend(adv_w8())        # W(0)
+    issue(dma_a()); ins.extend(adv_a())          # A(1)
+    issue(dma_w8()); ins.extend(adv_w8())        # W(1)
+    issue(dma_w8()); ins.extend(adv_w8())        # W(2)
+    ins += zero_acc()
+    ins += ["s_waitcnt vmcnt(16)", "s_barrier"]  # all but A(1) 8 + W(1) 4 + W(2) 4
+    ins += [f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
+    ins += reads8_w(0, 0) + reads8_a(0, 0)
+    ins += ["s_waitcnt lgkmcnt(8)"] + cvts(0) + ["s_waitcnt lgkmcnt(0)"]
+    return ins
+
+
+def phase(set_mfma, set_next, khalf_next, pcs, adv, load_next):
+    """64 MFMAs on fragment set `set_mfma`; behind them: the raw W / A reads of (set_next, khalf_next), their converts, and the
+    DMA pieces `pcs` (m0 set in slot k, load in slot k + 1)."""
+    ins = []
+    rw = reads8_w(set_next, khalf_next) if load_next else []
+    ra = reads8_a(set_next, khalf_next) if load_next else []
+    cv = cvts(set_next) if load_next else []
+    pcs, adv = list(pcs), list(adv)
+    flat = [x for pr in pcs for x in pr]                 # m0 set, load, m0 set, load ...
+    for k in range(64):
+        ins.append(mfma(set_mfma, k))
+        if k < 8 and rw:
+            ins.append(rw.pop(0))
+        elif 8 <= k < 16 and ra:
+            ins.append(ra.pop(0))
+        if flat and k < 48:
+            ins.append(flat.pop(0))
+        if k == 23 and load_next:
+            ins.append("s_waitcnt lgkmcnt(8)")           # the eight raw W reads (issued first) have landed
+        if 24 <= k < 56 and cv:
+            ins.append(cv.pop(0))
+    assert not rw and not ra and not cv and not flat
+    ins += adv
+    if load_next:
+        ins.append("s_waitcnt lgkmcnt(0)")
+    return ins
+
+
+def body2(dmaa, dmaw, nxt, wait):
+    ins = phase(0, 1, 1, [], [], True)
+    if nxt:
+        ins += [f"s_waitcnt vmcnt({wait})", "s_barrier"]
+        ins += rot_wrd8()
+        ins += [f"v_xor_b32 %{LA(0)}, 0x8000, %{LA(0)}", f"v_xor_b32 %{LA(1)}, 0x8000, %{LA(1)}",
+                f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
+    else:
+        ins.append("s_barrier")
+    pcs = (dma_a() if dmaa else []) + (dma_w8() if dmaw else [])
+    adv = (adv_a() if dmaa else []) + (adv_w8() if dmaw else [])
+    ins += phase(1, 0, 0, pcs, adv, nxt)
+    return ins
+
+
+def emit_v2():
+    """cnt = nk - 3 full bodies, then t = nk-3 (A only), nk-2 (no DMA), nk-1 (last).  Needs nk >= 4."""
+    lines = prologue2()
+    lines += ["1:"]
+    lines += body2(True, True, True, 4)
+    lines += [f"s_sub_u32 %{CNT}, %{CNT}, 1", f"s_cmp_lg_u32 %{CNT}, 0", "s_cbranch_scc1 1b"]
+    lines += body2(True, False, True, 4)
+    lines += body2(False, False, True, 0)
+    lines += body2(False, False, False, 0)
+    lines += ["s_nop 15", "s_nop 15"]
+    return lines
+
+
 def write_macro(f, name, lines):
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
     f.write(f"// {name}: {len(lines)} instructions, {n_mfma} MFMAs\n")
@@ -298,6 +427,7 @@ def main():
         f.write("// GENERATED by tools/gen_gemm_loop.py - do not edit.  Hand-scheduled K loops of gemm_bf16_kernel<.., 256, 256, 2, 2, ..>.\n")
         write_macro(f, "RGN_GEMM_LOOP4W_ASM", emit_v0())
         write_macro(f, "RGN_GEMM_LOOP4W_RING_ASM", emit_v1())
+        write_macro(f, "RGN_GEMM_LOOP4W_W8_ASM", emit_v2())
         clob = [f'"a{n}"' for n in range(256)] + [f'"v{n}"' for n in range(FRAG0, 256)] + ['"memory"', '"scc"']
         f.write("#define RGN_GEMM_LOOP4W_CLOBBERS " + ", ".join(clob) + "\n")
     print(f"wrote {os.path.normpath(out)}")
