@@ -123,6 +123,39 @@ def bench_small():
             print(f"pair[{variant:>4}] {name:<18} M={M0}+{M1:<4} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF  (ideal@1150 {fl/1150e6:6.1f} us)")
 
 
+def bench_w8():
+    """fp8 (e4m3fn) weights: bf16 weights vs the three fp8 paths - tiles inside the hand-scheduled loop (round 3 default),
+    compiler-scheduled fp8 tiles (RGN_W8_ASM=0), widen-once (RGN_W8_WIDEN_MIN_M=1) - cold weights (every launch a different copy)."""
+    shapes = [("v1p2 R kvq+mlp x2", 9088, 21504, 3072), ("v1p2 R proj_out x2", 9088, 3072, 15360), ("v1p2 F kvq+mlp", 33280, 21504, 3072),
+              ("v1p2 F proj_out", 33280, 3072, 15360), ("R kvq+mlp", 1536, 21504, 3072), ("R proj_out", 1536, 3072, 15360),
+              ("R5% kvq+mlp", 708, 21504, 3072), ("R5% proj_out", 708, 3072, 15360)]
+    only = os.environ.get("GEMM_ONLY")
+    for name, M, N, K in shapes:
+        if only and only not in name:
+            continue
+        A, b = rnd(M, K), rnd(N)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        ncopy = max(2, int(600e6 // (N * K)))
+        W16 = [rnd(N, K) * 0.05 for _ in range(max(2, ncopy // 2))]
+        W8 = [ops.quantize_w8(rnd(N, K) * 0.05) for _ in range(ncopy)]
+        st = {"i": 0}
+
+        def run(Ws):
+            st["i"] = (st["i"] + 1) % len(Ws)
+            ops.gemm(A, Ws[st["i"]], b, out)
+        fl = 2.0 * M * N * K
+        rows = [("bf16 W", W16, {}), ("fp8 asm loop", W8, dict(RGN_W8_ASM="1", RGN_W8_WIDEN_MIN_M="0")),
+                ("fp8 compiler tiles", W8, dict(RGN_W8_ASM="0", RGN_W8_WIDEN_MIN_M="0")),
+                ("fp8 widen once", W8, dict(RGN_W8_ASM="0", RGN_W8_WIDEN_MIN_M="1"))]
+        for label, Ws, env in rows:
+            for k in ("RGN_W8_ASM", "RGN_W8_WIDEN_MIN_M"):
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            med, best = timeit(lambda: run(Ws), iters=5, inner=15)
+            print(f"w8 {name:<20} M={M:<6} N={N:<6} K={K:<6} {label:<20} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF")
+        del W16, W8, A, out
+
+
 def bench_region():
     """The region-partition ops (O(L * 64) bytes -> launch-latency bound; achieved GB/s reported for
     honesty) next to the oracle's CPU time for the same call."""
@@ -185,5 +218,6 @@ if __name__ == "__main__":
     if "gemm" in which: bench_gemm()
     if "small" in which: bench_small()
     if "region" in which: bench_region()
+    if "w8" in which: bench_w8()
     if "attn" in which: bench_attn()
     if "gemv" in which: bench_gemv()
