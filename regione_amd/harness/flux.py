@@ -325,9 +325,9 @@ class FluxAttnProcessor:
                 # streams, but queries, attention and the output projection only for the image rows the caller reads; the
                 # text stream's output of this block feeds nothing
                 lo, hi = T, T + n_out
-                ops.gemm_pair(ws.nrm[T:R], attn.w_kvq[:2 * d], attn.b_kvq[:2 * d], wide[T:R, :2 * d],
-                              ws.nrm[:T], attn.w_add_kvq[:2 * d], attn.b_add_kvq[:2 * d], wide[:T, :2 * d])
-                ops.gemm(ws.nrm[lo:hi], attn.w_kvq[2 * d:], attn.b_kvq[2 * d:], wide[lo:hi, 2 * d:3 * d])
+                ops.gemm_pair(ws.nrm[T:R], ops.wrows(attn.w_kvq, None, 2 * d), attn.b_kvq[:2 * d], wide[T:R, :2 * d],
+                              ws.nrm[:T], ops.wrows(attn.w_add_kvq, None, 2 * d), attn.b_add_kvq[:2 * d], wide[:T, :2 * d])
+                ops.gemm(ws.nrm[lo:hi], ops.wrows(attn.w_kvq, 2 * d, None), attn.b_kvq[2 * d:], wide[lo:hi, 2 * d:3 * d])
                 ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
                                        k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
                 q = wide[lo:hi, 2 * d:3 * d]
@@ -357,8 +357,8 @@ class FluxAttnProcessor:
             # proj_out only for the rows the caller reads - the text and condition-image rows of this block's output feed
             # nothing.  (Region steps keep the one-launch path: their K/V rows carry the fp16 round trip of quirk A-3.)
             lo, hi = T, T + n_out
-            ops.gemm(ws.nrm[:R], attn.w_kvqm[:2 * d], attn.b_kvqm[:2 * d], wide[:, :2 * d])
-            ops.gemm(ws.nrm[lo:hi], attn.w_kvqm[2 * d:], attn.b_kvqm[2 * d:], wide[lo:hi, 2 * d:], epilogue=ops.EPI_GELU,
+            ops.gemm(ws.nrm[:R], ops.wrows(attn.w_kvqm, None, 2 * d), attn.b_kvqm[:2 * d], wide[:, :2 * d])
+            ops.gemm(ws.nrm[lo:hi], ops.wrows(attn.w_kvqm, 2 * d, None), attn.b_kvqm[2 * d:], wide[lo:hi, 2 * d:], epilogue=ops.EPI_GELU,
                      gelu_from_col=d)
             ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
                                    vt_slab, kv_rows)
@@ -647,8 +647,8 @@ class FluxTransformer2DModel:
         """Store the trunk's block GEMM weights (QKV(+MLP), out, FeedForward, proj_out of every block: > 99 % of the
         parameters) as OCP e4m3fn with one fp32 scale per output channel (ops.quantize_w8).  Activations, biases, norms,
         embedders and the AdaLN table stay bf16.  The GEMMs then read half the weight bytes; arithmetic is bf16 MFMA on the
-        exactly converted values, the scale multiplies the fp32 accumulator (rgn_gemm_w8*).  The last-block row skipping
-        (which slices weight rows) is switched off for a quantised trunk."""
+        exactly converted values, the scale multiplies the fp32 accumulator (rgn_gemm_w8*).  Row slices of a quantised
+        weight (the last block's row skipping) go through ops.wrows, which slices the scales with it."""
         def q(obj, name):
             w = getattr(obj, name, None)
             if w is not None and w.dtype == torch.bfloat16:
@@ -793,7 +793,7 @@ class FluxTransformer2DModel:
                                           joint_attention_kwargs), out_rows=out_rows))
             handle = BranchHandle(len(self._batch) - 1)
             return (handle,) if not return_dict else _Cfg(sample=handle)
-        if not SKIP_UNREAD_ROWS or getattr(self, "_fp8", False):
+        if not SKIP_UNREAD_ROWS:
             out_rows = None
         M, T = hidden_states.shape[1], encoder_hidden_states.shape[1]
         Mo = M if out_rows is None else min(int(out_rows), M)
@@ -812,7 +812,7 @@ class FluxTransformer2DModel:
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
-        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo if (SKIP_UNREAD_ROWS and not getattr(self, "_fp8", False)) else None)
+        ctx = FwdCtx(ws, T, M, mods, tag=(joint_attention_kwargs or {}).get("tag"), out_rows=Mo if SKIP_UNREAD_ROWS else None)
         for block in self.transformer_blocks:
             block(hidden_states=ws.x[T:R], encoder_hidden_states=ws.x[:T], temb=ctx, image_rotary_emb=image_rotary_emb)
         for block in self.single_transformer_blocks:
@@ -861,12 +861,11 @@ def _run_multi(self, recs):
     ws = self._ws_for_stream()
     ws.ensure(tot, max(T + M for T, M in zip(Ts, Ms)), nb)
     views = [WsView(ws, b, i) for i, b in enumerate(bases)]
-    fp8 = getattr(self, "_fp8", False)
     ctxs, ropes = [], []
     emb_x, emb_c = [], []
     for r, v, T, M in zip(recs, views, Ts, Ms):
         hidden, enc_hs, pooled, timestep, guidance, rope, _, jkw = r["args"]
-        out_rows = r["out_rows"] if (SKIP_UNREAD_ROWS and not fp8) else None
+        out_rows = r["out_rows"] if SKIP_UNREAD_ROWS else None
         Mo = M if out_rows is None else min(int(out_rows), M)
         emb_x.append(ops.Problem(hidden[0], self.x_embedder_weight, self.x_embedder_bias, v.x[T:T + M]))
         enc = enc_hs[0]
@@ -879,7 +878,7 @@ def _run_multi(self, recs):
         if mods is None:
             temb = self.time_text_embed(ts, gd, pooled)
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
-        ctxs.append(FwdCtx(v, T, M, mods, tag=(jkw or {}).get("tag"), out_rows=Mo if (SKIP_UNREAD_ROWS and not fp8) else None))
+        ctxs.append(FwdCtx(v, T, M, mods, tag=(jkw or {}).get("tag"), out_rows=Mo if SKIP_UNREAD_ROWS else None))
         ropes.append(rope)
     ops.gemm_group(emb_x)
     ops.gemm_group(emb_c)

@@ -187,6 +187,16 @@ def quantize_w8(W: torch.Tensor):
     return q
 
 
+def wrows(W: torch.Tensor, lo: Optional[int] = None, hi: Optional[int] = None) -> torch.Tensor:
+    """W[lo:hi] (output channels) of a GEMM weight; for a quantised weight the per-channel scales are sliced with it (a plain
+    slice of the tensor would lose the `_rgn_scale` attribute)."""
+    v = W[lo:hi]
+    s = getattr(W, "_rgn_scale", None)
+    if s is not None:
+        v._rgn_scale = s[lo:hi]
+    return v
+
+
 def _wscale(W: torch.Tensor) -> Optional[torch.Tensor]:
     if W.dtype != FP8:
         return None

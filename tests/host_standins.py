@@ -223,3 +223,22 @@ class QwenImageEditPipeline(_Base):
 
 class QwenImageEditPlusPipeline(QwenImageEditPipeline):
     pass
+
+
+
+# factories for tools/edit_driver.py --pipeline_factory tests.host_standins:make_<family> (this image has no diffusers /
+# checkpoints: the stand-ins exercise the hosted end-to-end protocol and its report)
+def make_flux():
+    return FluxKontextPipeline(stub_trunk("flux"))
+
+
+def make_step1x():
+    return Step1XEditPipeline(stub_trunk("step1x"))
+
+
+def make_step1x_v1p2():
+    return Step1XEditPipelineV1P2(stub_trunk("step1x"))
+
+
+def make_qwen():
+    return QwenImageEditPipeline(stub_trunk("qwen"))

@@ -386,6 +386,29 @@ def test_edit_driver_timing_protocol(tmp_path):
     assert all(os.path.exists(out / f"item_{i}.latent.pt") for i in range(3))
 
 
+@pytest.mark.parametrize("family", ["flux", "step1x_v1p2"])
+def test_edit_driver_hosted_end_to_end_stage_timing(tmp_path, family):
+    """tools/edit_driver.py --pipeline_factory: the reference drivers' END-TO-END protocol on a stock pipeline object
+    (`RegionEHelper(pipe).enable(); pipe(image=, prompt=)`), reporting encode / loop / decode wall-clock per item and on
+    average, RegionE and full-token through the same hosted call."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    items = tmp_path / "data.jsonl"
+    items.write_text("\n".join(json.dumps({"instruction": f"edit number {i}", "key": f"synthetic/item_{i}"}) for i in range(2)))
+    out = tmp_path / "result"
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.path.join(root, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "edit_driver.py"), "--image_path", str(items), "--use_regione",
+                        "--compare", "--size", "256", "--threshold", "0.5", "--erosion_dilation", "--output_dir", str(out),
+                        "--pipeline_factory", f"tests.host_standins:make_{family}"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.load(open(out / "time_consuming.json"))
+    assert rep["num_item"] == 2 and len(rep["stages_per_item"]) == 2
+    for st in [rep["stages"], rep["full_token"]["stages"]] + rep["stages_per_item"]:
+        assert set(st) == {"encode_s", "loop_s", "decode_s"} and st["loop_s"] > 0 and st["encode_s"] >= 0 and st["decode_s"] >= 0
+    assert rep["ave_time_consuming"] >= rep["stages"]["loop_s"] and rep["speedup"] > 0 and rep["loop_speedup"] > 0
+
+
 def test_qwen_toy_mmdit_vs_reference_fixture(golden):
     """The Qwen-Image-Edit patch set on the HIP engine against the fixture produced by the REFERENCE's own Qwen
     __call__ + transformer forward + two-cache tagged processors (tests/golden/qwen_toy_bf16.npz): plan and edited ids
@@ -540,7 +563,7 @@ def test_degenerate_partitions_nothing_or_everything_edited(threshold, expect):
     assert "".join(trace["kind"]) == "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04)).replace("S", "F")
 
 
-@pytest.mark.parametrize("family", ["flux", "step1x_v1p2", "qwen"])
+@pytest.mark.parametrize("family", ["flux", "step1x_v1p2", "qwen", "step1x_v1p2_fp8"])
 def test_last_block_skips_rows_nothing_reads_same_result(family, monkeypatch):
     """harness/flux.py `out_rows`: the pipelines read only `[:, :latents.size(1)]` of a forward, so in a full step the last
     single block computes queries / MLP / attention / proj_out (and norm_out / proj_out) for the latent rows only.  Same
@@ -561,6 +584,8 @@ def test_last_block_skips_rows_nothing_reads_same_result(family, monkeypatch):
         cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
         wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
         pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+        if family.endswith("fp8"):           # quantised trunk: the weight-row slices of the skipping path carry their scales (ops.wrows)
+            pipe.transformer.quantize_fp8_()
     cu = lambda t: t.cuda() if t is not None else None
     lat, img, prompt, y = [cu(t) for t in synth.make_edit_inputs(h, w, 32, cfg, seed=9, dtype=torch.bfloat16)]
     _, _, nprompt, ny = [cu(t) for t in synth.make_edit_inputs(h, w, 24, cfg, seed=10, dtype=torch.bfloat16)]
