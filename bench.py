@@ -480,9 +480,9 @@ def main():
     if dist is not None:
         result["collectives"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_in_world_of_one": bool(force)}
     # PMC passes cannot run inside the timed region (counter collection serialises kernels): the per-launch HBM-side
-    # traffic comes from a separate rocprofv3 --pmc run of THIS command (tools/pmc_traffic.py -> profiles/r02_pmc_traffic.json),
+    # traffic comes from a separate rocprofv3 --pmc run of THIS command (tools/pmc_traffic.py -> profiles/r03_pmc_traffic.json),
     # quoted only when that file was measured on the same kernel sources (csrc_sha16); otherwise null
-    pmc, pmc_file = {}, "profiles/r02_pmc_traffic.json"
+    pmc, pmc_file = {}, "profiles/r03_pmc_traffic.json"
     try:
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         if pmc.get("csrc_sha16") != csrc_hash():

@@ -232,12 +232,19 @@ def make_flux():
     return FluxKontextPipeline(stub_trunk("flux"))
 
 
+def _with_connector(pipe):
+    # the trunk class defines `connector` as a METHOD (the fixtures' pass-through stub), which wins over a registered
+    # sub-module in attribute lookup: shadow it on the instance, like tests/test_hosted_pipelines.py does
+    object.__setattr__(pipe.transformer, "connector", ToyConnector().to(torch.bfloat16))
+    return pipe
+
+
 def make_step1x():
-    return Step1XEditPipeline(stub_trunk("step1x"))
+    return _with_connector(Step1XEditPipeline(stub_trunk("step1x")))
 
 
 def make_step1x_v1p2():
-    return Step1XEditPipelineV1P2(stub_trunk("step1x"))
+    return _with_connector(Step1XEditPipelineV1P2(stub_trunk("step1x")))
 
 
 def make_qwen():
