@@ -368,6 +368,34 @@ def test_fit_gamma_tool_and_non_28_step_run_on_gpu():
     assert O.psnr(out, ref) >= 40.0
 
 
+@pytest.mark.parametrize("name", ["toy_bf16_all", "toy_bf16_none"])
+def test_toy_mmdit_partition_edge_cases_vs_reference_fixture(golden, name):
+    """K_e = L (every token edited: the region path on the full token set) and K_e = 0 (no token edited: region steps carry
+    the text rows only, zero-row image problems in every launch) on the HIP engine against the fixtures the REFERENCE's own
+    __call__ produced for these thresholds: same plan, same lengths, ids exact, latents >= 40 dB."""
+    g = golden(name)
+    h, w, T = g["h"], g["w"], g["T"]
+    cfg = synth.FluxConfig(**synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=g["w_std"])
+    lat, _, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=g["seed"], dtype=torch.bfloat16)
+    img = golden("toy_bf16")["image_latents"]
+    pipe = _toy_pipe(wts, cfg)
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=g["threshold"])
+    helper.enable()
+    trace = {}
+    out = pipe(image=img.cuda(), prompt_embeds=prompt.cuda(), pooled_prompt_embeds=pooled.cuda(), height=h * 16, width=w * 16,
+               latents=lat.cuda(), guidance_scale=2.5, return_dict=False, trace=trace)[0].cpu()
+    assert "".join(trace["kind"]) == "".join(g["kinds"].tolist())
+    M = pipe._regione_manager
+    assert M.edited_ids.shape[1] == (h * w if name.endswith("all") else 0)
+    assert [x.shape[1] for x in trace["latents"]] == g["len"].tolist()
+    for i in (5, 6, 15, 27):
+        if trace["latents"][i].shape[1]:
+            assert O.psnr(trace["latents"][i].cpu(), g[f"lat{i}"]) > 40.0, i
+    assert torch.isfinite(out.float()).all() and O.psnr(out, g["final"]) >= 40.0
+
+
 def test_edit_driver_timing_protocol(tmp_path):
     """tools/edit_driver.py: the reference drivers' protocol (jsonl items, 3 warm-ups, synchronised wall-clock per item,
     time_consuming.json with the reference's keys) on the toy engine."""

@@ -447,6 +447,48 @@ def gen_kv_and_toy(ns):
         print("   lens:", rec["len"], " K_e =", rec["edited_ids"].shape[1])
 
 
+def gen_toy_edges(ns):
+    """Edge cases of the partition through the reference's own FLUX __call__ + forward + processors at toy dims, on the
+    condition latent of `toy_bf16`: threshold 1.1 -> EVERY token edited (K_e = L: the region path runs on the full token set,
+    partial K/V update of every image row) and threshold -1.0 -> NO token edited (K_e = 0: region steps carry the text rows
+    only; recorded as whatever the reference does, including an exception)."""
+    base = load_npz("toy_bf16")
+    dtype = torch.bfloat16
+    cfg = synth.FluxConfig(**synth.TOY)
+    h = w = 16
+    L, T = h * w, 32
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=dtype, w_std=0.05)
+    latents, _, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=42, dtype=dtype)
+    ids_full = synth.flux_latent_ids(h, w)
+    for name, thr in (("toy_bf16_all", 1.1), ("toy_bf16_none", -1.0)):
+        model = ref_stubs.FluxTransformer2DModel(in_channels=cfg.in_channels, n_double=cfg.n_double, n_single=cfg.n_single,
+                                                 heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim,
+                                                 pooled_dim=cfg.pooled_dim, axes_dim=cfg.axes_dim).to(dtype)
+        load_weights_into(model, wts)
+        model.eval()
+        pipe = make_fake_pipeline(ns, model, latents, base["image_latents"], ids_full, prompt, pooled, T)
+        rcfg = dict(num_inference_steps=28, warmup_step=6, post_step=2, refresh_step="16", threshold=thr,
+                    cache_threshold=0.04, erosion_dilation=True)
+        rec = {k: [] for k in ("noise_pred", "prev_sample", "len", "ids_len", "prev_refresh", "next_refresh", "latents")}
+        err = ""
+        try:
+            with torch.no_grad():
+                run_reference_loop(ns, pipe, rcfg, h, w, rec)
+        except Exception as e:                  # the reference's own behaviour on this input IS the fixture
+            err = f"{type(e).__name__}: {e}"
+        d = dict(h=h, w=w, T=T, seed=42, threshold=thr, w_std=0.05, error=err, len=np.array(rec["len"]),
+                 steps_completed=len(rec["latents"]))
+        if not err:
+            d.update(final=rec["final"], kinds=np.array(rec["kinds"]), edited_ids=rec["edited_ids"].to(torch.int32),
+                     np_sum=np.array([float(x.double().sum()) for x in rec["noise_pred"]]),
+                     lat_sum=np.array([float(x.double().sum()) for x in rec["latents"]]))
+            for i in (5, 6, 15, 27):
+                d[f"np{i}"] = rec["noise_pred"][i]
+                d[f"lat{i}"] = rec["latents"][i]
+        save(name, d)
+        print("  ", name, "error:" if err else "ok", err[:120], " lens:", rec["len"][:8])
+
+
 class FakeTransformerB2:
     """Batch-2 elementwise stand-in for Step1X's batched CFG forward (Step1XEdit/inplace.py:381-399):
     row 0 (cond) is pulled towards target_pos, row 1 (uncond) towards target_neg."""
@@ -1005,6 +1047,8 @@ def main():
         gen_kv_and_toy(ns)
     if "toycfg" in which or "toy" in which:
         gen_toy_cfg(ns)
+    if "toyedges" in which or "toy" in which:
+        gen_toy_edges(ns)
     if "step1x" in which or not sys.argv[1:]:
         gen_step1x_loop(ns)
     if "qwen" in which or not sys.argv[1:]:
