@@ -20,6 +20,12 @@
 //     max is only raised - and O rescaled - when some row's tile max exceeds it by > 2^8;
 //   * XCD-aware block map: consecutive (head, q-block) items stay on one XCD so a head's K/V
 //     (4.4 MB at Skv = 8704) is fetched into that XCD's L2 once.
+// Two kernels share this design.  `attention_asm_kernel` (the default whenever Skv is a multiple of 64): 8 waves, the KV loop is
+// ONE hand-scheduled asm statement (attn_loop_asm.inc, tools/gen_attn_loop.py) in which each wave overlaps its own phases -
+// MFMA S(t+1) = K(t+1) Q^T under the exp2 / bf16 packing of P(t), MFMA O += V^T(t) P(t)^T under the row sums and the max of
+// S(t+1) - over a five-stage LDS-DMA ring; <1> = equal KV split pieces, <2> = stream-K runs of the flattened (item, KV tile)
+// steps for remainders (attention_schedule picks per launch; partials merged by attention_combine[_sk]_kernel).
+// `attention_kernel` (compiler-scheduled, 4 or 8 waves): ragged KV lengths, tiny query sets, RGN_ATTN_ASM=0.
 #include "common.h"
 #include <stdlib.h>
 #include <utility>
