@@ -104,3 +104,53 @@ def test_branch_stream_policy_first_pair_of_a_step_kind_runs_in_order(monkeypatc
     order = []
     a, b = D.run_cfg_branches(None, lambda: order.append("cond") or 1, lambda: order.append("uncond") or 2, concurrent=False)
     assert (a, b) == (1, 2) and order == ["cond", "uncond"]
+
+
+
+def test_cfg_branches_batched_protocol_records_then_executes_in_call_order(monkeypatch):
+    """regione_amd.dist.run_cfg_branches(batch_on=transformer): between begin_batch() and end_batch() each branch's forward call
+    only records and returns a handle that remembers the indexing applied to it; end_batch() executes once and the handles
+    resolve in call order.  RGN_BATCH_BRANCHES=0 and transformers without the protocol keep two forwards."""
+    import torch
+    from regione_amd import dist as D
+    from regione_amd.harness.flux import BranchHandle
+
+    class Tr:
+        def __init__(self):
+            self.log, self._batch = [], None
+
+        def begin_batch(self):
+            self._batch = []
+            self.log.append("begin")
+
+        def abort_batch(self):
+            self._batch = None
+            self.log.append("abort")
+
+        def end_batch(self):
+            recs, self._batch = self._batch, None
+            self.log.append(("end", len(recs)))
+            return [torch.full((1, 6, 4), float(r)) for r in recs]
+
+        def __call__(self, tag):
+            if self._batch is None:
+                self.log.append(("eager", tag))
+                return (torch.full((1, 6, 4), float(tag)),)
+            self._batch.append(tag)
+            return (BranchHandle(len(self._batch) - 1),)
+    tr = Tr()
+    monkeypatch.setenv("RGN_BATCH_BRANCHES", "1")
+    pos, neg = D.run_cfg_branches(None, lambda: tr(7)[0][:, :4], lambda: tr(9)[0][:, :2], batch_on=tr)
+    assert tr.log == ["begin", ("end", 2)] and pos.shape == (1, 4, 4) and neg.shape == (1, 2, 4)
+    assert float(pos[0, 0, 0]) == 7.0 and float(neg[0, 0, 0]) == 9.0
+    tr.log.clear()
+    monkeypatch.setenv("RGN_BATCH_BRANCHES", "0")
+    pos, neg = D.run_cfg_branches(None, lambda: tr(7)[0][:, :4], lambda: tr(9)[0][:, :2], batch_on=tr)
+    assert tr.log == [("eager", 7), ("eager", 9)] and float(neg[0, 0, 0]) == 9.0
+    # a failing branch aborts the recording
+    tr.log.clear()
+    monkeypatch.setenv("RGN_BATCH_BRANCHES", "1")
+    import pytest
+    with pytest.raises(ZeroDivisionError):
+        D.run_cfg_branches(None, lambda: tr(1)[0], lambda: 1 / 0, batch_on=tr)
+    assert tr.log == ["begin", "abort"] and tr._batch is None

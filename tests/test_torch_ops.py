@@ -8,11 +8,14 @@ import regione_amd.torch_ops as T
 
 def test_ops_are_registered_with_schemas():
     assert set(T.registered()) == {"arp_partition", "gather_rows", "scatter_rows_", "split_euler_step", "avd_apply",
-                                   "cfg_combine", "kv_partial_update_", "kv_partial_update_pair_", "region_attention"}
+                                   "cfg_combine", "kv_partial_update_", "kv_partial_update_pair_", "kv_partial_update_group_",
+                                   "region_attention"}
     s = str(torch.ops.regione_mi.scatter_rows_.default._schema)
     assert "Tensor(a!) dst" in s
     s = str(torch.ops.regione_mi.kv_partial_update_.default._schema)
     assert "Tensor(b!) k_cache" in s and "Tensor(c!) vt_cache" in s
+    s = str(torch.ops.regione_mi.kv_partial_update_group_.default._schema)       # batched CFG branches: tensor-list arguments
+    assert "Tensor(a!)[] q_out" in s and "Tensor(b!)[] k_cache" in s and "Tensor?[] kv_rows" in s and "int[] row_base" in s
 
 
 def test_fake_kernels_give_shapes_without_a_gpu():
