@@ -841,3 +841,85 @@ def test_gemm_fp8_split_k_pieces_in_the_hand_scheduled_loop(nsplit, monkeypatch)
     assert torch.equal(outs[0], outs[1])
     ref = F.linear(A.cpu().float(), (Wq.float() * Wq._rgn_scale[:, None]).cpu(), b.cpu().float())
     assert rel_err(outs[0].cpu(), ref) < 4e-3
+
+
+
+@pytest.mark.parametrize("case", ["gelu_576", "gate_288", "bias_ragged", "group_qkv", "fp8_gelu"])
+def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case, monkeypatch):
+    """Round 3: the tiles of a launch that do not fill a whole round of the 256 workgroup slots run as QUADRANTS (128 x 128 blocks,
+    two per CU) of the same tile list instead of being cut along K - no partials, no reduce pass, and per output element the same
+    accumulation order as an unsplit launch: RGN_GEMM_QUARTER=2 (forced) == RGN_GEMM_SPLIT=0 (one plain launch), bit for bit, for
+    every epilogue, ragged edges, the fused Q/K/V epilogue of a two-branch group with gathered cache rows, and fp8 weights."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(len(case))
+
+    def run():
+        if case in ("gelu_576", "fp8_gelu"):
+            M, N, K = 2944, 12288, 3072                       # 576 tiles = 2 rounds + 64
+            A, b = bf(torch.randn(M, K, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+            W = bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+            if case == "fp8_gelu":
+                W = ops.quantize_w8(W)
+            return (A, W, b), lambda o: ops.gemm(A, W, b, o, epilogue=ops.EPI_GELU), (M, N)
+        if case == "gate_288":
+            M, N, K = 1536, 12288, 3072                       # 288 tiles = 1 round + 32
+            A, b = bf(torch.randn(M, K, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+            W, gate = bf(torch.randn(N, K, generator=g) * 0.05).cuda(), bf(torch.randn(N, generator=g)).cuda()
+            x = bf(torch.randn(M, N, generator=g)).cuda()
+            return None, lambda o: (o.copy_(x), ops.gemm(A, W, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)), (M, N)
+        if case == "bias_ragged":
+            M, N, K = 2377, 9100 // 8 * 8, 1024               # ragged rows / columns: quadrants past the edge exit early
+            A, b = bf(torch.randn(M, K, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+            W = bf(torch.randn(N, K, generator=g) * 0.05).cuda()
+            return None, lambda o: ops.gemm(A, W, b, o), (M, N)
+        raise AssertionError
+    if case != "group_qkv":
+        _, fn, (M, N) = run()
+        outs = []
+        for env in (dict(RGN_GEMM_QUARTER="2"), dict(RGN_GEMM_SPLIT="0", RGN_GEMM_QUARTER="0")):
+            for k in ("RGN_GEMM_QUARTER", "RGN_GEMM_SPLIT"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            o = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
+            fn(o)
+            torch.cuda.synchronize()
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
+        return
+    # two CFG branches x (image, text) problems, fused Q/K/V epilogue, gathered cache rows on the image problems
+    H, K = 24, 3072
+    D, N = H * 128, 3 * H * 128
+    Mi, Ts, S = 1024, (512, 384), 4096
+    Wi, Wt = bf(torch.randn(N, K, generator=g) * 0.02).cuda(), bf(torch.randn(N, K, generator=g) * 0.02).cuda()
+    bi = bf(torch.randn(N, generator=g) * 0.1).cuda()
+    wq, wk = bf(1 + 0.1 * torch.randn(128, generator=g)).cuda(), bf(1 + 0.1 * torch.randn(128, generator=g)).cuda()
+    Ai = [bf(torch.randn(Mi, K, generator=g)).cuda() for _ in Ts]
+    At = [bf(torch.randn(t, K, generator=g)).cuda() for t in Ts]
+    res = []
+    for env in (dict(RGN_GEMM_QUARTER="2"), dict(RGN_GEMM_SPLIT="0", RGN_GEMM_QUARTER="0")):
+        for k in ("RGN_GEMM_QUARTER", "RGN_GEMM_SPLIT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        probs, keep = [], []
+        for b, T in enumerate(Ts):
+            skv = T + S
+            pad = ops.padded(skv)
+            ang = torch.rand(skv, 64, generator=torch.Generator().manual_seed(b)) * 6.28
+            rope = (ang.cos().repeat_interleave(2, 1).contiguous().cuda(), ang.sin().repeat_interleave(2, 1).contiguous().cuda())
+            ids = torch.randperm(S, generator=torch.Generator().manual_seed(7 + b))[:Mi].sort().values
+            rows = torch.cat([torch.arange(T), T + ids]).cuda()
+            rq = (rope[0][rows].contiguous(), rope[1][rows].contiguous())
+            ks, vs = torch.zeros(pad, D, dtype=torch.bfloat16, device="cuda"), torch.zeros(D, pad, dtype=torch.bfloat16, device="cuda")
+            out = torch.zeros(T + Mi, N, dtype=torch.bfloat16, device="cuda")
+            common = dict(wq=wq, wk=wk, rope_q=rq, rope_k=rope, k_slab=ks, vt_slab=vs, H=H, k_col=0, v_col=D, q_col=2 * D, kv_rows=rows)
+            probs += [ops.Problem(Ai[b], Wi, bi, out[T:], epi=ops.qkv_epilogue(row_base=T, fp16_roundtrip=True, **common)),
+                      ops.Problem(At[b], Wt, bi, out[:T], epi=ops.qkv_epilogue(row_base=0, **common))]
+            keep.append((out, ks, vs))
+        ops.gemm_group(probs, epilogue=3)
+        torch.cuda.synchronize()
+        res.append(keep)
+    for (o0, k0, v0), (o1, k1, v1) in zip(*res):
+        assert torch.equal(o0[:, 2 * D:], o1[:, 2 * D:]) and torch.equal(k0, k1) and torch.equal(v0, v1)
+        assert float(k0.float().abs().sum()) > 0
