@@ -269,8 +269,93 @@ def body1(dmaa, dmaw, nxt, wait):
     return ins
 
 
+def body1e(dmaa, dmaw, nxt, wait):
+    """Round 3 (the shipped ring variant; GEMM_LOOP_EARLY_BARRIER=0 regenerates the round-2 schedule `body1`): the tile barrier in
+    the MIDDLE of phase 1 instead of at the phase boundary.  The 16 set-1 reads go out in the first 16 MFMA slots; at slot BAR
+    every wave has its tile-t fragments in registers, so the stage is free there already: the 8 A pieces of tile t+2 follow in the
+    rest of phase 1 (one instruction per two MFMAs), the 8 W pieces of tile t+3 are spread over the whole of phase 2 (one per eight
+    MFMAs) next to the 16 reads of the next tile (one per two MFMAs, first half) - half the LDS-DMA pieces per phase, none next to
+    the set-1 reads, never two DMA-related instructions in adjacent slots.  An LDS-DMA piece costs the issuing wave ~60 cycles among
+    bare MFMAs but 100-185 in a phase that already carries 8 pieces + 16 ds_read_b128 (MI355X_MICROARCH.md), and a wave of this
+    kernel is the only one on its SIMD: every cycle it spends issuing is a cycle the MFMA pipe may run dry.  Same MFMAs, same order:
+    bit-identical accumulators.  Measured, same box, cold weights (2 boxes): proj_out (K = 15360) 1268 -> 1357 TFLOP/s, ff2
+    (K = 12288) 1340 -> 1430, K = 3072 shapes +-1 %; in the pipeline every shape gains (kvq+mlp 1240 -> 1262, proj_out 1304 -> 1377,
+    ff2 1201 -> 1311): 20.14 -> 20.52 steps/s (+1.9 %).  Variants measured next to it: all 16 pieces packed into phase 1 behind
+    the barrier (one per MFMA) -6 %; barrier at slot 16 / 24 / 28, reads-first phase 2: within +-0.3 % of this one."""
+    BAR = int(os.environ.get("GEMM_LOOP_BAR", "20"))
+    WPH1 = os.environ.get("GEMM_LOOP_WPH1") == "1"          # the W pieces in phase 1 too (phase 2 then carries reads only)
+    STEP = int(os.environ.get("GEMM_LOOP_STEP", "2"))       # MFMA slots per DMA-related instruction in phase 1
+    ins = []
+    r1 = reads1(1, 1)
+    pa = (dma_a() if dmaa else []) + ((dma_w() if dmaw else []) if WPH1 else [])
+    flat = [x for pr in pa for x in pr]
+    for k in range(64):
+        ins.append(mfma(0, k))
+        if k < 16:
+            ins.append(r1.pop(0))
+        if k == BAR:
+            ins.append("s_waitcnt lgkmcnt(0)")
+            if nxt:
+                ins += [f"s_waitcnt vmcnt({wait})", "s_barrier"]
+                ins += rot_wrd()
+                ins += [f"v_xor_b32 %{LA(0)}, 0x8000, %{LA(0)}", f"v_xor_b32 %{LA(1)}, 0x8000, %{LA(1)}",
+                        f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
+            else:
+                ins.append("s_barrier")
+        if k > BAR and flat and (k - BAR - 1) % STEP == 0:
+            ins.append(flat.pop(0))
+    assert not flat, len(flat)
+    if dmaa:
+        ins += adv_a()
+    if dmaw and WPH1:
+        ins += adv_w()
+    r0 = reads1(0, 0) if nxt else []
+    pw = (dma_w() if dmaw else []) if not WPH1 else []
+    flatw = [x for pr in pw for x in pr]
+    P2 = os.environ.get("GEMM_LOOP_P2", "spread")
+    for k in range(64):
+        ins.append(mfma(1, k))
+        g = k % 4
+        if P2 == "a":                               # reads and W pieces interleaved in the first half
+            if g in (2, 3) and r0:
+                ins.append(r0.pop(0))
+            elif g in (0, 1) and flatw and k >= 2:
+                ins.append(flatw.pop(0))
+        elif P2 == "spread":                        # reads one per two slots in the first half, W pieces one per eight slots over the phase
+            if k % 2 == 0 and r0:
+                ins.append(r0.pop(0))
+            if k % 8 in (5, 7) and flatw:
+                ins.append(flatw.pop(0))
+        elif P2 == "spread2":                       # 16 reads in the first 16 slots, W pieces one per eight slots over the whole phase
+            if k < 16 and r0:
+                ins.append(r0.pop(0))
+            if k % 8 in (5, 7) and flatw:
+                ins.append(flatw.pop(0))
+        elif P2 == "readsfirst":                    # 16 reads in the first 16 slots, then the W pieces (one instruction per 3 slots)
+            if k < 16 and r0:
+                ins.append(r0.pop(0))
+            if k >= 16 and (k - 16) % 3 == 0 and flatw:
+                ins.append(flatw.pop(0))
+    assert not r0 and not flatw, (len(r0), len(flatw))
+    if dmaw and not WPH1:
+        ins += adv_w()
+    if nxt:
+        ins.append("s_waitcnt lgkmcnt(0)")
+    return ins
+
+
 def emit_v1():
     """cnt = nk - 3 full bodies (t = 0 .. nk-4), then t = nk-3 (A only), nk-2 (no DMA), nk-1 (last).  Needs nk >= 4."""
+    if os.environ.get("GEMM_LOOP_EARLY_BARRIER", "1") == "1":
+        lines = prologue1()
+        lines += ["1:"]
+        lines += body1e(True, True, True, 8)
+        lines += [f"s_sub_u32 %{CNT}, %{CNT}, 1", f"s_cmp_lg_u32 %{CNT}, 0", "s_cbranch_scc1 1b"]
+        lines += body1e(True, False, True, 8)
+        lines += body1e(False, False, True, 0)
+        lines += body1e(False, False, False, 0)
+        lines += ["s_nop 15", "s_nop 15"]
+        return lines
     lines = prologue1()
     lines += ["1:"]
     lines += body1(True, True, True, 8)
@@ -398,15 +483,67 @@ def body2(dmaa, dmaw, nxt, wait):
     return ins
 
 
+def body2e(dmaa, dmaw, nxt, wait):
+    """The fp8 loop on the early-barrier schedule of body1e: barrier at slot BAR8 of phase 1 (every read of tile t - raw W and A -
+    has landed), the converts of set 1 and the 8 A pieces behind it, the 4 W pieces spread over phase 2."""
+    BAR = int(os.environ.get("GEMM_LOOP_BAR8", "24"))
+    ins = []
+    rw, ra, cv = reads8_w(1, 1), reads8_a(1, 1), cvts(1)
+    flat = [x for pr in (dma_a() if dmaa else []) for x in pr]
+    for k in range(64):
+        ins.append(mfma(0, k))
+        if k < 8:
+            ins.append(rw.pop(0))
+        elif k < 16:
+            ins.append(ra.pop(0))
+        if k == BAR:
+            ins.append("s_waitcnt lgkmcnt(0)")
+            if nxt:
+                ins += [f"s_waitcnt vmcnt({wait})", "s_barrier"]
+                ins += rot_wrd8()
+                ins += [f"v_xor_b32 %{LA(0)}, 0x8000, %{LA(0)}", f"v_xor_b32 %{LA(1)}, 0x8000, %{LA(1)}",
+                        f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
+            else:
+                ins.append("s_barrier")
+        if k > BAR and cv:
+            ins.append(cv.pop(0))
+        if k > BAR and flat and (k - BAR - 1) % 2 == 0:
+            ins.append(flat.pop(0))
+    assert not cv and not flat and not rw and not ra
+    if dmaa:
+        ins += adv_a()
+    rw, ra, cv = (reads8_w(0, 0), reads8_a(0, 0), cvts(0)) if nxt else ([], [], [])
+    flatw = [x for pr in (dma_w8() if dmaw else []) for x in pr]
+    for k in range(64):
+        ins.append(mfma(1, k))
+        if k < 8 and rw:
+            ins.append(rw.pop(0))
+        elif 8 <= k < 16 and ra:
+            ins.append(ra.pop(0))
+        if k % 8 in (5, 7) and flatw:
+            ins.append(flatw.pop(0))
+        if k == 23 and nxt:
+            ins.append("s_waitcnt lgkmcnt(8)")           # the eight raw W reads (issued first) have landed
+        if 24 <= k < 56 and cv:
+            ins.append(cv.pop(0))
+    assert not rw and not ra and not cv and not flatw
+    if dmaw:
+        ins += adv_w8()
+    if nxt:
+        ins.append("s_waitcnt lgkmcnt(0)")
+    return ins
+
+
 def emit_v2():
     """cnt = nk - 3 full bodies, then t = nk-3 (A only), nk-2 (no DMA), nk-1 (last).  Needs nk >= 4."""
+    b2 = body2e if os.environ.get("GEMM_LOOP_EARLY_BARRIER", "1") == "1" else body2
     lines = prologue2()
     lines += ["1:"]
-    lines += body2(True, True, True, 4)
+    lines += b2(True, True, True, 4)
     lines += [f"s_sub_u32 %{CNT}, %{CNT}, 1", f"s_cmp_lg_u32 %{CNT}, 0", "s_cbranch_scc1 1b"]
-    lines += body2(True, False, True, 4)
-    lines += body2(False, False, True, 0)
-    lines += body2(False, False, False, 0)
+    lines += b2(True, False, True, 4)
+    lines += b2(False, False, True, 0)
+    lines += b2(False, False, False, 0)
     lines += ["s_nop 15", "s_nop 15"]
     return lines
 
