@@ -37,7 +37,7 @@ ACC = [TMP + 8 + i for i in range(4)]           # row-sum accumulators
 T_R = [TMP + 12 + i for i in range(4)]          # rescale temporaries
 K_TILE, STAGE, NSTAGE = 16384, 32768, 5
 LDS_END = STAGE * NSTAGE
-CFG = dict(D=4, novalu=False, noread=False, prio=False, pkfma=False, pkadd=False, dot2sum=False, dephase=False)      # generator knobs (main() emits several variants)
+CFG = dict(D=4, novalu=False, noread=False, prio=False, pkfma=False, pkadd=False, dot2sum=False, dephase=False, dmaspread=False)      # generator knobs (main() emits several variants)
 
 
 def v(n, w=1):
@@ -257,6 +257,31 @@ def dma_issue(st):
     advance(st, "stg_d")
 
 
+def dma_split():
+    """dma_issue cut into a prologue (scalar set-up), the four pieces (callables) and an epilogue (offset / stage advance): the
+    pieces are issued one at a time behind QK MFMAs 0, 2, 4, 6 of phase X (ATTN_DMA_AT) instead of back to back behind the tile
+    barrier, where nothing is queued on the matrix pipe yet (an LDS-DMA piece costs the issuing wave ~60 cycles among MFMAs already
+    queued, more otherwise).  Round 3, same box: full step 1202 -> 1212 TFLOP/s, region 25 % 965 -> 982, v1p2 2048^2 region 1203 -> 1220;
+    placements 1,5,9,13 / 3,7,11,15 / 9,11,13,15 within 0.5 % of it.  ATTN_DMA_SPREAD=0 regenerates the round-2 schedule."""
+    def pro(st):
+        st.emit("s_min_u32 %[stmp], %[tk], %[tk_last]")
+        st.emit("s_min_u32 %[stmp2], %[tv], %[tv_last]")
+        st.emit("s_add_u32 %[sdst], %[stg_d], %[wdst]")
+
+    def piece(kind, p):
+        def f(st):
+            st.emit(f"s_add_u32 m0, %[sdst], {(K_TILE if kind == 'v' else 0) + p * 1024}")
+            st.emit("s_nop 0")
+            st.emit(f"buffer_load_dwordx4 %[d{kind}{p}], %[r{kind}], %[{'stmp2' if kind == 'v' else 'stmp'}] offen lds")
+        return f
+
+    def epi(st):
+        st.emit("s_add_u32 %[tk], %[tk], %[kadv]")
+        st.emit("s_add_u32 %[tv], %[tv], 128")
+        advance(st, "stg_d")
+    return pro, [piece("k", 0), piece("k", 1), piece("v", 0), piece("v", 1)], epi
+
+
 def interleave(st, mfmas, fillers, per_gap):
     """emit the MFMA callbacks with `per_gap[i]` fillers behind MFMA i (fillers: strings or callables(st))"""
     fi = 0
@@ -282,7 +307,7 @@ def spread(n_fill, n_gaps, first=0):
     return gaps
 
 
-def phase_x(st, p, full):
+def phase_x(st, p, full, dma=None):
     """X(t), S(t) in set p: exp of tile t; with `full` also the QK MFMAs of tile t+1 into set 1-p.
     Entry: K fragments 0..D-1 of tile t+1 requested (slots 0..D-1).  Exit: V fragments 0..D-1 of tile t requested.
     Fragment i of a phase lives in slot i % 8; it is requested D MFMAs before its use: behind MFMA i-D-1... i.e. read(i + D)
@@ -298,6 +323,7 @@ def phase_x(st, p, full):
             v_read(st, g)
         return
     mf = []
+    at = [int(x) for x in os.environ.get("ATTN_DMA_AT", "0,2,4,6").split(",")]
     for f in range(16):
         def m(st, f=f):
             if f + D < 16:
@@ -305,6 +331,11 @@ def phase_x(st, p, full):
             qk_mfma(st, f, q)
             if f >= 8 and f - 8 < D:                       # slot f-8 is free now: V prefetch for Y(t)
                 v_read(st, f - 8)
+            if dma is not None and f in at:                # one LDS-DMA piece of tile t+4 behind this MFMA
+                pieces, epi = dma
+                pieces[at.index(f)](st)
+                if f == at[-1]:
+                    epi(st)
         mf.append(m)
     gaps = spread(len(vops), 16)
     interleave(st, mf, vops, gaps)
@@ -346,13 +377,22 @@ def body(st, p, full, tag, role="A"):
     finished Y(t-1) (the stage tile t+4 overwrites), and role B's early X(t) reads K(t+1), which landed by barrier t-1."""
     rescale_block(st, tag)
 
+    spread_dma = CFG.get("dmaspread") and role == "A"
+    dma = None
+
     def tile_barrier():
+        nonlocal dma
         st.emit("s_waitcnt vmcnt(4)")                      # tile t+2 has landed (t+3 may be in flight)
         st.emit("s_barrier")
-        dma_issue(st)                                      # tile t+4 -> the stage of tile t-1
+        if spread_dma:
+            pro, pieces, epi = dma_split()
+            pro(st)
+            dma = (pieces, epi)                            # issued one by one inside phase X
+        else:
+            dma_issue(st)                                  # tile t+4 -> the stage of tile t-1
     if full and role == "A":
         tile_barrier()
-    phase_x(st, p, full)
+    phase_x(st, p, full, dma)
     if full:
         advance(st, "stg_k")                               # next X reads K of tile t+2
     if full and role == "B":
@@ -457,7 +497,8 @@ def main():
         for name, kw in variants:
             CFG.update(dict(D=4, novalu=False, noread=False, prio=False, pkfma=os.environ.get("ATTN_PKFMA", "0") == "1",
                             pkadd=os.environ.get("ATTN_PKADD", "0") == "1", dot2sum=os.environ.get("ATTN_DOT2SUM", "0") == "1",
-                            dephase=os.environ.get("ATTN_DEPHASE", "0") == "1"))
+                            dephase=os.environ.get("ATTN_DEPHASE", "0") == "1",
+                            dmaspread=os.environ.get("ATTN_DMA_SPREAD", "1") == "1"))
             CFG.update(kw)
             lines = emit()
             n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
