@@ -776,8 +776,10 @@ class FluxTransformer2DModel:
         recs, self._batch = self._batch, None
         if not recs:
             return []
-        if len(recs) == 1:
-            return [self._run(*recs[0]["args"], out_rows=recs[0]["out_rows"])[0]]
+        # the batched pass is built on the fused Q/K/V epilogue (256-column = two-head blocks) and carries exactly the two CFG
+        # branches; anything else runs the recorded forwards one after the other
+        if len(recs) != 2 or not FUSE_QKV or self.cfg_model.heads % 2:
+            return [self._run(*r["args"], out_rows=r["out_rows"])[0] for r in recs]
         return self._run_multi(recs)
 
     def _run(self, hidden_states, encoder_hidden_states, pooled, timestep, guidance, image_rotary_emb, return_dict,
@@ -849,7 +851,7 @@ def _run_multi(self, recs):
     branch against that branch's K / V^T.  The LAST block (and norm_out / proj_out) runs per branch on the single-branch code,
     which knows how to skip the rows nothing reads."""
     nb = len(recs)
-    assert 2 <= nb <= 2, "batched forwards carry the two CFG branches"
+    assert nb == 2, "batched forwards carry the two CFG branches"
     d = self.cfg_model.d
     Ms = [r["args"][0].shape[1] for r in recs]
     Ts = [r["args"][1].shape[1] for r in recs]
