@@ -124,10 +124,10 @@ class KernelTimer:
             timer.shapes.setdefault((M, 0, N, K), []).append((s, e))
             return r
 
-        def attention(q, k_slab, vt_slab, out, skv, H, scale=None):
+        def attention(q, k_slab, vt_slab, out, skv, H, scale=None, workspace=None, score_bound=0.0):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            r = timer._orig_attn(q, k_slab, vt_slab, out, skv, H, scale)
+            r = timer._orig_attn(q, k_slab, vt_slab, out, skv, H, scale, workspace, score_bound)
             e.record()
             timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * H * 128))
             if q.shape[0] < skv:             # region step: the K / V^T cache slabs are streamed once per launch

@@ -279,6 +279,15 @@ int rgn_qk_norm_rope_store(void* qkv, int ld, int k_col, int v_col, int q_col, i
 int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O,
                   int ldo, int Sq, int Skv, int H, float scale, void* workspace, size_t workspace_bytes,
                   void* stream);
+/* The same with a caller-provided bound on the scores: the caller GUARANTEES |q . k| * scale <= score_bound for every (query,
+ * key) pair of the call - e.g. q and k are RMS-normalised per head (norm_q / norm_k, inplace.py:760-763) and rotated, so
+ * |q . k| <= 128 * max|w_q| * max|w_k|.  With score_bound * log2(e) <= 96 the hand-scheduled kernel then computes
+ * P = exp2(s * log2 e) without a running row maximum (no per-tile max, no rescale: ~11 % fewer VALU instructions per KV tile); the
+ * result is the same softmax up to fp32 / bf16 rounding.  A bound of 0 (or one that is too large) = rgn_attention.  A violated
+ * bound is the caller's error (overflow). */
+int rgn_attention_bounded(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O, int ldo,
+                          int Sq, int Skv, int H, float scale, float score_bound, void* workspace, size_t workspace_bytes,
+                          void* stream);
 /* Optional fp32 scratch for the round-aware schedule: (head, q-block) items that do not fill a whole
  * round of the chip's workgroup slots are cut along KV (equal pieces or stream-K runs, chosen per launch) and merged by a
  * combine kernel.  NULL disables the split (results are identical up to fp32 summation order).  The returned size (128 MiB)

@@ -92,6 +92,8 @@ SIGNATURES = {
                                _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "rgn_attention": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                       _c_float, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_attention_bounded": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                              _c_float, _c_float, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_attention_workspace_bytes": [_c_int, _c_int],
 }
 _RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_attention_workspace_bytes": C.c_size_t,

@@ -50,6 +50,10 @@ struct AttnArgs {
     // SPLIT mode every item is cut into nsplit KV ranges whose partial (O, m, l) go to `ws`.
     int item_offset, nitems_launch, nsplit;
     int dephase;                 // hand-scheduled loop: 0 = every wave in role A, 1 = waves 4..7 in role B, 2 = odd waves in role B
+    // static softmax shift (rgn_attention_bounded): the caller guarantees |q . k| * scale <= bound for every pair, so
+    // P = exp2(S * c - static_m) cannot overflow or vanish and the loop keeps no running max (hand-scheduled kernel only)
+    int static_on;
+    float static_m;
     float* ws;
 };
 
@@ -342,7 +346,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 //        2 = stream-K: the (item, KV tile) steps of the launch, flattened item-major, are dealt out in equal contiguous
 //            runs to the gridDim.x workgroups; a run crosses at most one item boundary, so a workgroup works through one
 //            or two SEGMENTS (partials to slot 2 * unit + seg, attention_combine_sk_kernel merges).
-template <int SPLIT>
+template <int SPLIT, bool SM = false>
 __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g) {
     constexpr int NW = 8, QB = 256;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -389,7 +393,7 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
     }
     const int h = item / nQ, qb = item - h * nQ;
     const int q0 = qb * QB + wave * 32;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = SM ? g.static_m : -1e30f, l_run = 0.f;
     if (ntiles > 0) {
         // per-lane relative LDS addresses of the fragments (same swizzles as attention_kernel)
         uint32_t krel[8], vrel[4];
@@ -433,16 +437,29 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
         const float sl2e = g.scale_log2e;
         const uint64_t sl2e2 = ((uint64_t)__float_as_uint(sl2e) << 32) | __float_as_uint(sl2e);    // both halves: packed-fp32 operand
         uint32_t stmp, stmp2, sdst;
-        asm volatile(RGN_ATTN_LOOP_ASM
-                     : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k),
-                       [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2),
-                       [sdst] "=&s"(sdst)
-                     : [krel0] "v"(krel[0]), [krel1] "v"(krel[1]), [krel2] "v"(krel[2]), [krel3] "v"(krel[3]), [krel4] "v"(krel[4]),
-                       [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]),
-                       [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]),
-                       [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last),
-                       [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e), [sl2e2] "s"(sl2e2), [ones2] "s"(0x3f803f80u), [role] "s"(role)
-                     : RGN_ATTN_LOOP_CLOBBERS);
+        if constexpr (SM) {
+            asm volatile(RGN_ATTN_LOOP_SM_ASM
+                         : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k),
+                           [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2),
+                           [sdst] "=&s"(sdst)
+                         : [krel0] "v"(krel[0]), [krel1] "v"(krel[1]), [krel2] "v"(krel[2]), [krel3] "v"(krel[3]), [krel4] "v"(krel[4]),
+                           [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]),
+                           [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]),
+                           [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last),
+                           [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e), [sl2e2] "s"(sl2e2), [ones2] "s"(0x3f803f80u), [role] "s"(role)
+                         : RGN_ATTN_LOOP_CLOBBERS);
+        } else {
+            asm volatile(RGN_ATTN_LOOP_ASM
+                         : [m_run] "+&v"(m_run), [l_run] "+&v"(l_run), [tk] "+&s"(tk), [tv] "+&s"(tv), [stg_k] "+&s"(stg_k),
+                           [stg_v] "+&s"(stg_v), [stg_d] "+&s"(stg_d), [cnt] "+&s"(cnt), [stmp] "=&s"(stmp), [stmp2] "=&s"(stmp2),
+                           [sdst] "=&s"(sdst)
+                         : [krel0] "v"(krel[0]), [krel1] "v"(krel[1]), [krel2] "v"(krel[2]), [krel3] "v"(krel[3]), [krel4] "v"(krel[4]),
+                           [krel5] "v"(krel[5]), [krel6] "v"(krel[6]), [krel7] "v"(krel[7]), [vrel0] "v"(vrel[0]), [vrel1] "v"(vrel[1]),
+                           [vrel2] "v"(vrel[2]), [vrel3] "v"(vrel[3]), [dk0] "v"(dk[0]), [dk1] "v"(dk[1]), [dv0] "v"(dv[0]), [dv1] "v"(dv[1]),
+                           [qptr] "v"(qptr), [rk] "s"(rk), [rv] "s"(rv), [kadv] "s"(kadv), [tk_last] "s"(tk_last), [tv_last] "s"(tv_last),
+                           [wdst] "s"(wdst), [rem] "s"(rem), [sl2e] "s"(sl2e), [sl2e2] "s"(sl2e2), [ones2] "s"(0x3f803f80u), [role] "s"(role)
+                         : RGN_ATTN_LOOP_CLOBBERS);
+        }
     }
     // O^T accumulator: a[db * 16 + r] (zero when this split piece had no tiles - but then the launch has none either)
     const float l_other = __shfl_xor(l_run, 32, 64);
@@ -578,11 +595,13 @@ static int launch_attention_asm(const AttnArgs& g, int nblocks, hipStream_t st) 
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !attr[dev]) {
-        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)attention_asm_kernel<SPLIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (dev >= 0 && dev < 64) attr[dev] = true;
     }
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL((attention_asm_kernel<SPLIT>), dim3(nblocks), dim3(512), LDS, st, g);
+    if (g.static_on) hipLaunchKernelGGL((attention_asm_kernel<SPLIT, true>), dim3(nblocks), dim3(512), LDS, st, g);
+    else hipLaunchKernelGGL((attention_asm_kernel<SPLIT, false>), dim3(nblocks), dim3(512), LDS, st, g);
     return check_launch("attention_asm_kernel");
 }
 
@@ -685,6 +704,12 @@ size_t rgn_attention_workspace_bytes(int Sq, int H) {
 
 int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O, int ldo,
                   int Sq, int Skv, int H, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    return rgn_attention_bounded(Q, ldq, k_slab, vt_slab, skv_pad, O, ldo, Sq, Skv, H, scale, 0.0f, workspace, workspace_bytes, stream);
+}
+
+int rgn_attention_bounded(const void* Q, int ldq, const void* k_slab, const void* vt_slab, int skv_pad, void* O, int ldo,
+                          int Sq, int Skv, int H, float scale, float score_bound, void* workspace, size_t workspace_bytes,
+                          void* stream) {
     if (Sq == 0) return 0;
     if (!Q || !k_slab || !vt_slab || !O || Sq < 0 || Skv <= 0 || H <= 0 || (skv_pad % 64) || skv_pad < Skv ||
         (ldq % 8) || (ldo % 8))
@@ -694,6 +719,14 @@ int rgn_attention(const void* Q, int ldq, const void* k_slab, const void* vt_sla
     g.ldq = ldq; g.ldo = ldo; g.skv_pad = skv_pad; g.Sq = Sq; g.Skv = Skv; g.H = H;
     g.scale_log2e = scale * 1.4426950408889634f;
     g.item_offset = 0; g.nitems_launch = 0; g.nsplit = 1; g.ws = nullptr;
+    // static softmax shift: with |scores| <= score_bound, exp2(s * log2e) stays within 2^+-96 for score_bound * log2e <= 96 - row
+    // sums over any Skv < 2^31 and the PV accumulators stay far inside fp32 (and bf16 for P).  RGN_ATTN_STATIC_MAX=0: A/B switch.
+    {
+        const char* e = getenv("RGN_ATTN_STATIC_MAX");
+        const float b2 = score_bound * 1.4426950408889634f;
+        g.static_on = (!(e && atoi(e) == 0) && score_bound > 0.0f && b2 <= 96.0f) ? 1 : 0;
+        g.static_m = 0.0f;
+    }
     { const char* e = getenv("RGN_ATTN_DEPHASE"); g.dephase = e ? atoi(e) : 0; }   // only meaningful for an ATTN_DEPHASE=1 build of the loop
     hipStream_t st = (hipStream_t)stream;
     // 8-wave workgroups (256 query rows share each K/V tile, 1 per CU) unless the query set is tiny

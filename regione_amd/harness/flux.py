@@ -284,6 +284,21 @@ class Attention:
     def set_processor(self, processor):
         self.processor = processor
 
+    def score_bound(self) -> float:
+        """A bound on |q . k| / sqrt(head_dim) for every (query, key) pair this module ever forms: q and k leave the per-head
+        RMSNorm with ||x^|| <= sqrt(head_dim) before the elementwise weight, and RoPE is a rotation, so
+        |q . k| <= head_dim * max|w_q| * max|w_k| (both streams' weights in a double-stream block) - times 1.05 for the bf16
+        roundings on the way.  Handed to rgn_attention_bounded, which then needs no running row maximum (used only while
+        bound * log2(e) <= 96; computed once per module, one small device read)."""
+        b = self.__dict__.get("_score_bound")
+        if b is None:
+            def amax(names):
+                ws = [getattr(self, n) for n in names if getattr(self, n, None) is not None]
+                return max(float(w.float().abs().max()) for w in ws)
+            b = 1.05 * self.head_dim * amax(("norm_q", "norm_added_q")) * amax(("norm_k", "norm_added_k")) / math.sqrt(self.head_dim)
+            self._score_bound = b
+        return b
+
     def __call__(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         # diffusers' Attention.forward: unknown cross-attention kwargs are dropped unless the processor's __call__ names them
         return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
@@ -331,7 +346,7 @@ class FluxAttnProcessor:
                 ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
                                        k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
                 q = wide[lo:hi, 2 * d:3 * d]
-                TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
+                TO.R.region_attention(q, k_slab, vt_slab, q, skv, H, -1.0, attn.score_bound())
                 g_img, _ = block.gates_msa(ctx)
                 ops.gemm(q, attn.w_out, attn.b_out, ws.x[lo:hi], epilogue=ops.EPI_GATE_RESID, gate=g_img, resid=ws.x[lo:hi])
                 return ws.x[T:R], ws.x[:T]
@@ -346,7 +361,7 @@ class FluxAttnProcessor:
                 ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k,
                                        k_slab, vt_slab, kv_rows, split_row=T, wq0=attn.norm_added_q, wk0=attn.norm_added_k)
             q = wide[:, 2 * d:3 * d]
-            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
+            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H, -1.0, attn.score_bound())
             g_img, g_txt = block.gates_msa(ctx)
             ops.gemm_pair(q[T:R], attn.w_out, attn.b_out, ws.x[T:R], q[:T], attn.w_add_out, attn.b_add_out, ws.x[:T],
                           epilogue=ops.EPI_GATE_RESID, gate0=g_img, resid0=ws.x[T:R], gate1=g_txt, resid1=ws.x[:T])
@@ -363,7 +378,7 @@ class FluxAttnProcessor:
             ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
                                    vt_slab, kv_rows)
             q = wide[lo:hi, 2 * d:3 * d]
-            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
+            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H, -1.0, attn.score_bound())
             return wide[lo:hi, 2 * d:]
         if fuse:
             TO.R.kv_partial_update_(ws.nrm[:R], attn.w_kvqm, attn.b_kvqm, wide, attn.norm_q, attn.norm_k, cos_q, sin_q, cos_k,
@@ -373,7 +388,7 @@ class FluxAttnProcessor:
             ops.qk_norm_rope_store(wide, 0, d, 2 * d, H, attn.norm_q, attn.norm_k, image_rotary_emb, rope_k, k_slab,
                                    vt_slab, kv_rows)
         q = wide[:, 2 * d:3 * d]
-        TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
+        TO.R.region_attention(q, k_slab, vt_slab, q, skv, H, -1.0, attn.score_bound())
         return wide[:, 2 * d:]                                       # cat([attn_output, mlp_hidden], dim=2)
 
 
@@ -408,7 +423,7 @@ class FluxAttnProcessor:
                                       3 * d if self.single else -1)
         for wsv, T, R, k_slab, vt_slab, skv in per:
             q = wsv.wide[:R, 2 * d:3 * d]
-            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H)
+            TO.R.region_attention(q, k_slab, vt_slab, q, skv, H, -1.0, attn.score_bound())
         if self.single:
             return
         group = []
@@ -637,6 +652,8 @@ class FluxTransformer2DModel:
         try_finish()
         if pend:
             raise KeyError(f"unconsumed weights: {sorted(pend)[:5]} ...")
+        for blk in list(self.transformer_blocks) + list(self.single_transformer_blocks):
+            blk.attn._score_bound = None                  # recomputed from the new norm weights on first use
         return self
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):

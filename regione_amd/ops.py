@@ -418,16 +418,18 @@ def attention_workspace(device) -> torch.Tensor:
 
 
 def attention(q: torch.Tensor, k_slab: torch.Tensor, vt_slab: torch.Tensor, out: torch.Tensor, skv: int, H: int,
-              scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q / out: [Sq, H*128] views (row stride free, may alias)."""
+              scale: Optional[float] = None, workspace: Optional[torch.Tensor] = None, score_bound: float = 0.0) -> torch.Tensor:
+    """q / out: [Sq, H*128] views (row stride free, may alias).  `score_bound` > 0: the caller's guarantee that every
+    |q . k| * scale is at most that (rgn_attention_bounded: no running max in the softmax)."""
     Sq = q.shape[0]
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
     if workspace is None:
         workspace = attention_workspace(q.device)
-    rc = _lib.lib().rgn_attention(_p(q), q.stride(0), _p(k_slab), _p(vt_slab), k_slab.shape[0], _p(out), out.stride(0),
-                                  Sq, skv, H, float(scale), _p(workspace), workspace.numel() * 4, _stream())
-    _lib.check(rc, "rgn_attention")
+    rc = _lib.lib().rgn_attention_bounded(_p(q), q.stride(0), _p(k_slab), _p(vt_slab), k_slab.shape[0], _p(out), out.stride(0),
+                                          Sq, skv, H, float(scale), float(score_bound), _p(workspace), workspace.numel() * 4,
+                                          _stream())
+    _lib.check(rc, "rgn_attention_bounded")
     return out
 
 

@@ -146,12 +146,12 @@ _define("kv_partial_update_group_",
         lambda *a, **k: None)
 
 
-def _region_attention(q, k_cache, vt_cache, out, skv, heads, scale=-1.0):
-    ops.attention(q, k_cache, vt_cache, out, skv, heads, scale if scale > 0 else None)
+def _region_attention(q, k_cache, vt_cache, out, skv, heads, scale=-1.0, score_bound=0.0):
+    ops.attention(q, k_cache, vt_cache, out, skv, heads, scale if scale > 0 else None, score_bound=score_bound)
 
 
 _define("region_attention",
-        "(Tensor q, Tensor k_cache, Tensor vt_cache, Tensor(a!) out, int skv, int heads, float scale=-1.0) -> ()",
+        "(Tensor q, Tensor k_cache, Tensor vt_cache, Tensor(a!) out, int skv, int heads, float scale=-1.0, float score_bound=0.0) -> ()",
         _region_attention, lambda *a, **k: None)
 
 
