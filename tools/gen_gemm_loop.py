@@ -61,6 +61,14 @@ def acc(i, j):
 
 
 def mfma(set_, k):
+    if os.environ.get("GEMM_LOOP_MFMA32") == "1":
+        # TIMING-ONLY experiment (wrong arithmetic): the same pipe time as half as many 32x32x16 instructions - does the loop gain
+        # from the freed issue slots?  slot k even: one 32x32x16 MFMA on accumulator block k/4 (two per block per k-half); k odd: none
+        if k % 2:
+            return "s_nop 0"
+        blk, kk = divmod(k // 2, 2)
+        b = blk * 16
+        return f"v_mfma_f32_32x32x16_bf16 a[{b}:{b + 15}], {frag(set_, 8 + (blk % 4) * 2 + kk)}, {frag(set_, (blk // 4) * 2 + kk)}, a[{b}:{b + 15}]"
     i, j = divmod(k, TN)
     return f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {frag(set_, 8 + j)}, {frag(set_, i)}, {acc(i, j)}"
 
