@@ -265,12 +265,30 @@ def test_qwen_full_dims_double_block_two_tagged_caches_full_store_then_region_up
     M.set_partition(e.unsqueeze(0).to(dev), u.unsqueeze(0).to(dev), box.flatten().to(torch.uint8).to(dev))
     st.edited_ids, st.unedited_ids = e.unsqueeze(0), u.unsqueeze(0)
     lat_e = torch.randn(1, e.numel(), 64, generator=torch.Generator().manual_seed(77)).to(torch.bfloat16)
+    seq = {}
     for tag in ("cond", "uncond"):
         out_hip = hip_forward(lat_e.to(dev), latent_ids[e], M.warmup_step, tag)
         out_ref = oracle_forward(lat_e, ids_full[e], st.warmup_step, tag)
         assert out_hip.shape == out_ref.shape == (1, e.numel(), 64)
         _check(f"qwen {tag} region-step output", out_hip, out_ref)
         _compare_branch_caches(f"qwen {tag} (update)", procs, prefixes, doubles, caches[tag], tag, wts, heads, Ts[tag], L,
+                               ropes[tag], e=e, u=u, stored=stored[tag])
+        seq[tag] = (out_hip.clone(), out_ref)
+    # the same region step with BOTH branches as one batched pass (the pipelines' default): 2944 rows per launch,
+    # per-branch K / V^T caches and rotary tables in the grouped Q/K/V epilogue - against the oracle and the two-forward outputs
+    from regione_amd import dist as D
+    M.current_step = M.warmup_step
+    t = ts[M.warmup_step].expand(1).to(torch.bfloat16)
+
+    def fwd(tag):
+        return pipe.transformer(hidden_states=lat_e.to(dev), timestep=t / 1000, encoder_hidden_states=embeds_d[tag],
+                                img_shapes=img_shapes, latent_ids=latent_ids[e], attention_kwargs={"tag": tag}, return_dict=False)[0]
+    both = D.run_cfg_branches(None, lambda: fwd("cond"), lambda: fwd("uncond"), batch_on=pipe.transformer)
+    torch.cuda.synchronize()
+    for tag, got in zip(("cond", "uncond"), both):
+        _check(f"qwen {tag} region-step output, batched pass", got, seq[tag][1])
+        _check(f"qwen {tag} batched pass vs two forwards", got, seq[tag][0], min_psnr=55.0, max_rel=5e-3)
+        _compare_branch_caches(f"qwen {tag} (update, batched)", procs, prefixes, doubles, caches[tag], tag, wts, heads, Ts[tag], L,
                                ropes[tag], e=e, u=u, stored=stored[tag])
 
 
