@@ -202,7 +202,7 @@ def test_qwen_full_dims_double_block_two_tagged_caches_full_store_then_region_up
     from regione_amd import RegionEHelper
     from regione_amd.harness import qwen as HQ
     dev = torch.device("cuda", 0)
-    cfg = synth.FluxConfig(**dict(synth.QWEN, n_double=1))
+    cfg = synth.FluxConfig(**dict(synth.QWEN, n_double=2))      # two blocks: the first one runs through the batched-branch code
     assert cfg.d == 3072 and cfg.joint_dim == 3584 and cfg.txt_norm
     wts = synth.make_flux_weights(cfg, seed=6, dtype=torch.bfloat16)
     h = w = 64
@@ -232,12 +232,12 @@ def test_qwen_full_dims_double_block_two_tagged_caches_full_store_then_region_up
         torch.cuda.synchronize()
         return out
 
-    ocfg = O.FluxCfg(n_double=1, n_single=0, heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim)
+    ocfg = O.FluxCfg(n_double=2, n_single=0, heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim)
     st = O.RegionState()
     st.set_parameters(28, 6, 2, "16", 0.88, 0.03, True)
     ids_full = torch.arange(2 * L)
     st.refresh(img, ids_full, Ts["cond"], h, w)
-    caches = {k: [O.KVCache()] for k in Ts}
+    caches = {k: [O.KVCache(), O.KVCache()] for k in Ts}
     ropes = {k: O.qwen_rope([(1, h, w), (1, h, w)], T) for k, T in Ts.items()}
     _, ots = O.flow_match_schedule(28, L)
     assert torch.equal(ots, ts.cpu())
@@ -249,8 +249,8 @@ def test_qwen_full_dims_double_block_two_tagged_caches_full_store_then_region_up
             return O.transformer_forward(wts, ocfg, st, caches[tag], x, embeds[tag], None, t / 1000, ids, None, None,
                                          rope_full=ropes[tag])
 
-    procs = [pipe.transformer.transformer_blocks[0].attn.processor]
-    prefixes, doubles = ["transformer_blocks.0"], (True,)
+    procs = [b.attn.processor for b in pipe.transformer.transformer_blocks]
+    prefixes, doubles = ["transformer_blocks.0", "transformer_blocks.1"], (True, True)
     x_full = torch.cat([lat, img], dim=1)
     store = M.warmup_step - 1
     stored = {}
