@@ -261,6 +261,8 @@ def qkv_epilogue(*, wq, wk, rope_q, rope_k, k_slab, vt_slab, H: int, k_col: int,
     assert vt_slab.shape == (H * 128, skv_pad) and k_slab.shape[1] == H * 128 and k_slab.is_contiguous() and vt_slab.is_contiguous()
     for t in (rope_q[0], rope_q[1], rope_k[0], rope_k[1]):
         assert t.dtype == torch.float32 and t.shape[1] == 128 and t.is_contiguous()
+    # the kernel reads 8-byte indices: an int32 tensor would be read past its end and scatter K / V to garbage cache rows
+    assert kv_rows is None or (kv_rows.dtype == torch.int64 and kv_rows.dim() == 1 and kv_rows.is_contiguous())
     e = _lib.QkvEpilogue(_p(wq), _p(wk), _p(rope_q[0]), _p(rope_q[1]), _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows),
                          _p(k_slab), _p(vt_slab), row_base, skv_pad, k_col, v_col, q_col, H, eps, int(fp16_roundtrip))
     e._keep = (wq, wk, rope_q, rope_k, kv_rows, k_slab, vt_slab)
@@ -401,6 +403,7 @@ def qk_norm_rope_store(qkv: torch.Tensor, k_col: int, v_col: int, q_col: int, H:
     M = qkv.shape[0]
     skv_pad = k_slab.shape[0]
     assert vt_slab.shape == (H * 128, skv_pad) and k_slab.shape[1] == H * 128
+    assert kv_rows is None or (kv_rows.dtype == torch.int64 and kv_rows.dim() == 1 and kv_rows.is_contiguous() and kv_rows.numel() >= M)
     rc = _lib.lib().rgn_qk_norm_rope_store(_p(qkv), qkv.stride(0), k_col, v_col, q_col, M, H, split_row, _p(wq0),
                                            _p(wk0), _p(wq1), _p(wk1), eps, _p(rope_q[0]), _p(rope_q[1]),
                                            _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows), _p(k_slab), _p(vt_slab), skv_pad,
