@@ -184,15 +184,26 @@ def LBO(kh):
     return f"[lbo{kh}]"
 
 
+ABL = os.environ.get("GEMM_LOOP_ABL", "")       # TIMING-ONLY ablations (wrong results): "noA" = no A pieces, no A fragment reads;
+#                                                   "noA+ld" = the same plus 16 direct global loads of A fragments per K tile
+
+
 def reads1(set_, khalf):
     out = []
     for f in range(8):
-        out.append(f"ds_read_b128 {frag(set_, f)}, %{LA(khalf)} offset:{f * 2048}")
+        if ABL == "noA+ld":
+            out.append(f"s_sub_u32 m0, %{KOFF}, 256\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 {frag(set_, f)}, %{OA(f)}, %{PA}, m0 offen offset:{khalf * 64}")
+        elif ABL == "noA":
+            out.append("s_nop 0")
+        else:
+            out.append(f"ds_read_b128 {frag(set_, f)}, %{LA(khalf)} offset:{f * 2048}")
         out.append(f"ds_read_b128 {frag(set_, 8 + f)}, %{LB(khalf)} offset:{f * 2048}")
     return out
 
 
 def dma_a():
+    if ABL:
+        return [("s_nop 0", "s_nop 0") for q in range(8)]
     return [(f"s_add_u32 m0, %{STG}, {q * 1024}", f"buffer_load_dwordx4 %{OA(q)}, %{PA}, %{KOFF} offen lds") for q in range(8)]
 
 
@@ -304,7 +315,7 @@ def body1e(dmaa, dmaw, nxt, wait):
         if k == BAR:
             ins.append("s_waitcnt lgkmcnt(0)")
             if nxt:
-                ins += [f"s_waitcnt vmcnt({wait})", "s_barrier"]
+                ins += [f"s_waitcnt vmcnt({wait + 24 if ABL == 'noA+ld' and wait else wait})", "s_barrier"]
                 ins += rot_wrd()
                 ins += [f"v_xor_b32 %{LA(0)}, 0x8000, %{LA(0)}", f"v_xor_b32 %{LA(1)}, 0x8000, %{LA(1)}",
                         f"v_add_u32 %{LB(0)}, %{WRD}, %{LBO(0)}", f"v_add_u32 %{LB(1)}, %{WRD}, %{LBO(1)}"]
