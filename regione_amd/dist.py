@@ -149,6 +149,15 @@ def make_cfg_pair(dist) -> CfgBranchPair:
 _side_streams = {}
 
 
+def side_stream(main):
+    """The side stream paired with `main` (one per caller stream, created on first use)."""
+    key = (main.device_index, main.cuda_stream)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=main.device)
+    return side
+
+
 def _branch_streams_mode() -> int:
     """RGN_BRANCH_STREAMS: 0 = the two forwards of a step run one after the other on the caller's stream (reference order),
     1 (default) = the uncond forward of a step that can profit runs on a side stream, 2 = of every computed step."""
@@ -204,10 +213,7 @@ def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch
         pos = run_cond()
         return pos, run_uncond()
     main = torch.cuda.current_stream()
-    key = (main.device_index, main.cuda_stream)
-    side = _side_streams.get(key)
-    if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=main.device)
+    side = side_stream(main)
     side.wait_stream(main)                       # fork: everything enqueued so far (latents, caches of earlier steps) is visible
     try:
         pos = run_cond()                         # host order stays cond -> uncond; the GPU runs them side by side

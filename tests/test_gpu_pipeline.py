@@ -787,8 +787,11 @@ def test_cfg_branches_batched_through_one_pass_bit_identical_to_two_forwards(fam
     helper.set_params(threshold=0.5)
     monkeypatch.setenv("RGN_BRANCH_STREAMS", "0")
     res = {}
-    for batched in ("1", "0"):
-        monkeypatch.setenv("RGN_BATCH_BRANCHES", batched)
+    # "1": the batched pass (second branch's attention on a side stream, the default), "1s": the batched pass on one stream,
+    # "0": two forwards
+    for batched in ("1", "1s", "0"):
+        monkeypatch.setenv("RGN_BATCH_BRANCHES", batched[0])
+        monkeypatch.setenv("RGN_ATTN_BRANCH_STREAMS", "0" if batched == "1s" else "1")
         van = pipe(**kw)[0].clone()
         helper.enable()
         trace = {}
@@ -796,7 +799,8 @@ def test_cfg_branches_batched_through_one_pass_bit_identical_to_two_forwards(fam
         torch.cuda.synchronize()
         res[batched] = (van, reg, pipe._regione_manager.edited_ids.clone(), [x.clone() for x in trace["noise_pred"]], "".join(trace["kind"]))
         helper.disable()
-    a, b = res["1"], res["0"]
+    a, b, c = res["1"], res["0"], res["1s"]
+    assert torch.equal(a[1], c[1]) and torch.equal(a[0], c[0]) and all(torch.equal(x, y) for x, y in zip(a[3], c[3]))
     assert a[4] == b[4] and "R" in a[4] and "F" in a[4]
     assert torch.equal(a[2], b[2]) and a[2].numel() > 0
     assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])), "a noise_pred of the batched pass differs from the two-forward run"
