@@ -137,9 +137,17 @@ class KernelTimer:
         ops.gemm, ops.attention, ops.gemm_pair = gemm, attention, gemm_pair
         ops.gemm_qkv, ops.gemm_qkv_pair = gemm_qkv, gemm_qkv_pair
         ops.gemm_group = gemm_group
+        # per-launch durations need launches that do not share the chip: the batched CFG pass keeps both branches' attention on
+        # one stream while the timer is installed (the throughput legs run without the timer and with the default)
+        self._prev_streams = os.environ.get("RGN_ATTN_BRANCH_STREAMS")
+        os.environ["RGN_ATTN_BRANCH_STREAMS"] = "0"
 
     def unwrap(self):
         import regione_amd.ops as ops
+        if self._prev_streams is None:
+            os.environ.pop("RGN_ATTN_BRANCH_STREAMS", None)
+        else:
+            os.environ["RGN_ATTN_BRANCH_STREAMS"] = self._prev_streams
         ops.gemm, ops.attention, ops.gemm_pair = self._orig_gemm, self._orig_attn, self._orig_pair
         ops.gemm_qkv, ops.gemm_qkv_pair = self._orig_qkv, self._orig_qkv_pair
         ops.gemm_group = self._orig_group
