@@ -34,6 +34,10 @@ extern "C" {
 
 int rgn_version(void);
 const char* rgn_last_error(void);
+/* The launch plan the GEMM planner chose for the last rgn_gemm_* call on this thread (introspection for tests and traces; the
+ * reference has no counterpart): bits 0-7 = K pieces of the remainder (1 = none), bit 8 = quarter-tile remainder, bit 10 =
+ * 256 x 256 tile geometry. */
+int rgn_gemm_last_plan(void);
 
 /* ------------------------------------------------------------------------------------------
  * a1/a2  Adaptive Region Partition.  Replaces token_selector (utils.py:282-354) + morphology

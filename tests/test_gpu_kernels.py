@@ -269,6 +269,9 @@ def test_gemm_round_aware_split_k_path():
     lin = (A.float() @ W.float().T + b.float())
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     ops.gemm(A, W, b, out)
+    from regione_amd import _lib
+    plan = _lib.lib().rgn_gemm_last_plan()
+    assert (plan & 0x400) and (plan & 0xff) > 1, f"the remainder was not cut along K (plan {plan:#x})"
     assert rel_err(out.cpu(), lin.cpu()) < 3e-3
     import os
     os.environ["RGN_GEMM_SPLIT"] = "0"
@@ -885,6 +888,9 @@ def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case, mon
             fn(o)
             torch.cuda.synchronize()
             outs.append(o)
+            from regione_amd import _lib
+            plan = _lib.lib().rgn_gemm_last_plan()
+            assert bool(plan & 0x100) == ("RGN_GEMM_SPLIT" not in env), f"unexpected launch plan {plan:#x} under {env}"
         assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
         return
     # two CFG branches x (image, text) problems, fused Q/K/V epilogue, gathered cache rows on the image problems
