@@ -169,7 +169,8 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
                 trace.setdefault("noise_pred", []).append(noise_pred.clone())
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
-                                                    prompt_embeds)                  # inplace.py:376-383
+                                                    prompt_embeds, noise_pred=noise_pred, image_latents=image_latents,
+                                                    negative_prompt_embeds=negative_prompt_embeds)                  # inplace.py:376-383
             latents, latent_ids = MANAGER.step(latents, latent_ids)
             if trace is not None:
                 trace.setdefault("latents", []).append(latents.clone())

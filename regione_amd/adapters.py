@@ -319,11 +319,24 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
                    latents=None, prompt_embeds=None, prompt_embeds_mask=None, negative_prompt_embeds=None,
                    negative_prompt_embeds_mask=None, output_type: str = "pil", return_dict: bool = True,
                    timesteps_truncate: float = 0.93, process_norm_power: float = 0.4, size_level=None, trace=None, sigmas=None,
-                   callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), **unused):
+                   callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), enable_thinking_mode=None,
+                   enable_reflection_mode=None, max_try_cnt=None, **unused):
     """Step1XEditPipeline / Step1XEditPipelineV1P2 `__call__` around the engine loop (Step1XEdit/inplace.py:185-330,:437-455;
-    Step1XEditV1P2/inplace.py:214-300).  Not hosted: v1p2's thinking / reflection retry loop (VLM prompting, :192-212)."""
-    _refuse_unused(_host_name(host) + ".__call__", unused)
+    Step1XEditV1P2/inplace.py:214-300).  Not hosted: v1p2's thinking / reflection retry loop (VLM prompting, :192-212) - the
+    v1p2 switches `enable_thinking_mode` / `enable_reflection_mode` / `max_try_cnt` (Step1XEditV1P2/inplace.py:107-109) are
+    accepted when they switch that loop OFF (the reference driver's own call, src/Step1X-Edit-v1p2/main.py:42-43,:69-77),
+    True raises NotImplementedError; left unspecified the hosted call runs ONE attempt without reflection (the reference's
+    signature default is reflection on: stated deviation)."""
     v1p2 = _host_name(host).endswith("V1P2")
+    think = dict(enable_thinking_mode=enable_thinking_mode, enable_reflection_mode=enable_reflection_mode, max_try_cnt=max_try_cnt)
+    if v1p2:
+        for k in ("enable_thinking_mode", "enable_reflection_mode"):
+            if think[k]:
+                raise NotImplementedError(f"{_host_name(host)}.__call__: {k}=True (the VLM thinking / reflection retry loop, "
+                                          "Step1XEditV1P2/inplace.py:192-212) is not hosted by the HIP loop; pass False")
+    else:                                   # v1p1 has no such arguments: a caller passing them gets the usual refusal
+        unused = dict(unused, **{k: v for k, v in think.items() if v is not None})
+    _refuse_unused(_host_name(host) + ".__call__", unused)
     dev = eng.transformer.device
     clk = _Clock(dev)
     exec_dev = getattr(host, "_execution_device", dev)

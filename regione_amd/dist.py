@@ -208,7 +208,9 @@ def run_cfg_branches(pair: Optional[CfgBranchPair], run_cond: Callable[[], torch
             batch_on.abort_batch()
             raise
         outs = batch_on.end_batch()
-        return pos.resolve(outs), neg.resolve(outs)
+        # a forward that did not record (a wrapped / replaced forward, or closures calling another object than `batch_on`)
+        # hands back real tensors: they ARE the two sequential results (advisor finding, round 3)
+        return tuple(o.resolve(outs) if hasattr(o, "resolve") else o for o in (pos, neg))
     if not (concurrent and torch.cuda.is_available()):
         pos = run_cond()
         return pos, run_uncond()

@@ -284,20 +284,39 @@ class Attention:
     def set_processor(self, processor):
         self.processor = processor
 
+    _NORMS_Q, _NORMS_K = ("norm_q", "norm_added_q"), ("norm_k", "norm_added_k")
+
+    def _norm_weights(self):
+        return [w for n in self._NORMS_Q + self._NORMS_K if (w := getattr(self, n, None)) is not None]
+
+    def _bound_key(self):
+        # in-place edits of the adopted norm weights (LoRA merge, .copy_) bump `_version`; a swapped tensor changes data_ptr
+        return tuple((w.data_ptr(), w._version) for w in self._norm_weights())
+
+    def _amax_pair(self):
+        """Device scalars (max|w_q|, max|w_k|) over both streams' norm weights - no host sync."""
+        def amax(names):
+            ws = [getattr(self, n).float().abs().max() for n in names if getattr(self, n, None) is not None]
+            return torch.stack(ws).max()
+        return torch.stack((amax(self._NORMS_Q), amax(self._NORMS_K)))
+
+    def _set_bound(self, aq: float, ak: float):
+        self._score_bound = 1.05 * self.head_dim * aq * ak / math.sqrt(self.head_dim)
+        self._score_bound_key = self._bound_key()
+
     def score_bound(self) -> float:
         """A bound on |q . k| / sqrt(head_dim) for every (query, key) pair this module ever forms: q and k leave the per-head
         RMSNorm with ||x^|| <= sqrt(head_dim) before the elementwise weight, and RoPE is a rotation, so
         |q . k| <= head_dim * max|w_q| * max|w_k| (both streams' weights in a double-stream block) - times 1.05 for the bf16
         roundings on the way.  Handed to rgn_attention_bounded, which then needs no running row maximum (used only while
-        bound * log2(e) <= 96; computed once per module, one small device read)."""
-        b = self.__dict__.get("_score_bound")
-        if b is None:
-            def amax(names):
-                ws = [getattr(self, n) for n in names if getattr(self, n, None) is not None]
-                return max(float(w.float().abs().max()) for w in ws)
-            b = 1.05 * self.head_dim * amax(("norm_q", "norm_added_q")) * amax(("norm_k", "norm_added_k")) / math.sqrt(self.head_dim)
-            self._score_bound = b
-        return b
+        bound * log2(e) <= 96).  Computed for every block in ONE device read when the weights are loaded
+        (`refresh_score_bounds`); the cached value is keyed on the norm weights' (data_ptr, _version), so an in-place change
+        after first use (advisor finding, round 3) recomputes it - that path costs one device-to-host read in the forward.
+        `RGN_ATTN_STATIC_MAX=0` switches the bounded softmax off altogether (the kernel then tracks the row maximum)."""
+        if self.__dict__.get("_score_bound") is None or self._score_bound_key != self._bound_key():
+            aq, ak = self._amax_pair().tolist()
+            self._set_bound(aq, ak)
+        return self._score_bound
 
     def __call__(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
         # diffusers' Attention.forward: unknown cross-attention kwargs are dropped unless the processor's __call__ names them
@@ -666,9 +685,17 @@ class FluxTransformer2DModel:
         try_finish()
         if pend:
             raise KeyError(f"unconsumed weights: {sorted(pend)[:5]} ...")
-        for blk in list(self.transformer_blocks) + list(self.single_transformer_blocks):
-            blk.attn._score_bound = None                  # recomputed from the new norm weights on first use
+        self.refresh_score_bounds()
         return self
+
+    def refresh_score_bounds(self):
+        """Attention.score_bound() of every block from the norm weights now in place: one stacked device read for the whole
+        trunk (instead of a device-to-host sync inside the first forward of each block)."""
+        attns = [blk.attn for blk in list(self.transformer_blocks) + list(self.single_transformer_blocks)]
+        attns = [a for a in attns if a._norm_weights()]
+        if attns:
+            for a, (aq, ak) in zip(attns, torch.stack([a._amax_pair() for a in attns]).tolist()):
+                a._set_bound(aq, ak)
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         return self.load_state_dict_stream(sd.items())
@@ -874,6 +901,12 @@ class BranchHandle:
             t = t[k]
         return t
 
+    def __getattr__(self, name):
+        # only indexing can be replayed: anything else a forward / pipeline applies before end_batch() needs the real tensor
+        raise AttributeError(f"BranchHandle.{name}: the transformer is recording a batched CFG pass (begin_batch ... end_batch) "
+                             "and its output does not exist yet - only [] indexing is deferred; set RGN_BATCH_BRANCHES=0 to "
+                             "run the two forwards one after the other")
+
 
 def _run_multi(self, recs):
     """`_run` for several recorded CFG branches (same latent rows, per-branch text, conditioning, rotary tables, cache tag)
@@ -990,12 +1023,19 @@ class FluxKontextPipeline:
         self.scheduler.set_timesteps(sigmas=sigmas, mu=mu)
         return latents, image_latents, latent_ids, text_ids, h_tok, w_tok
 
-    def _callback(self, cb, names, i, t, latents, prompt_embeds):
+    def _callback(self, cb, names, i, t, latents, prompt_embeds, **more):
         """`callback_on_step_end` with the reference's semantics (inplace.py:376-383): called with the tensors named in
-        `callback_on_step_end_tensor_inputs`; `latents` / `prompt_embeds` in the returned dict replace the loop's."""
+        `callback_on_step_end_tensor_inputs`; `latents` / `prompt_embeds` in the returned dict replace the loop's.  The
+        reference resolves the names with `locals()[k]`; here the loop hands over the ones a callback can meaningfully ask
+        for (latents, prompt_embeds, noise_pred, image_latents, negative_prompt_embeds) and any other name is refused with
+        the list instead of a bare KeyError in the middle of the loop (advisor finding, round 3)."""
         if cb is None:
             return latents, prompt_embeds
-        avail = {"latents": latents, "prompt_embeds": prompt_embeds}
+        avail = {"latents": latents, "prompt_embeds": prompt_embeds, **more}
+        unknown = [k for k in names if k not in avail]
+        if unknown:
+            raise ValueError(f"callback_on_step_end_tensor_inputs {unknown} not available in the hosted loop; "
+                             f"supported: {sorted(avail)}")
         out = cb(self, i, t, {k: avail[k] for k in names})
         out = dict(out) if out else {}
         return out.pop("latents", latents), out.pop("prompt_embeds", prompt_embeds)
@@ -1038,7 +1078,8 @@ class FluxKontextPipeline:
                 noise_pred = branch(prompt_embeds, pooled_prompt_embeds)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
-                                                    prompt_embeds)
+                                                    prompt_embeds, noise_pred=noise_pred, image_latents=image_latents,
+                                                    negative_prompt_embeds=negative_prompt_embeds)
         if not return_dict:
             return (latents,)
         return FluxPipelineOutput(images=latents)

@@ -155,7 +155,8 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
                 noise_pred = branch(prompt_embeds, "cond")
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
-                                                    prompt_embeds)
+                                                    prompt_embeds, noise_pred=noise_pred, image_latents=image_latents,
+                                                    negative_prompt_embeds=negative_prompt_embeds)
         if not return_dict:
             return (latents,)
         return QwenImagePipelineOutput(images=latents)

@@ -125,7 +125,8 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
             noise_pred = self._cfg(noise_pred, t, true_cfg_scale, timesteps_truncate, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
-                                                    prompt_embeds)
+                                                    prompt_embeds, noise_pred=noise_pred, image_latents=image_latents,
+                                                    negative_prompt_embeds=negative_prompt_embeds)
         if not return_dict:
             return (latents,)
         return Step1XEditPipelineOutput(images=latents)
@@ -163,7 +164,8 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
             noise_pred = TO.R.cfg_combine(outs[0], outs[1], true_cfg_scale, mode, process_norm_power)
             latents = self.scheduler.step(noise_pred, t, latents, return_dict=False)[0]
             latents, prompt_embeds = self._callback(callback_on_step_end, callback_on_step_end_tensor_inputs, i, t, latents,
-                                                    prompt_embeds)
+                                                    prompt_embeds, noise_pred=noise_pred, image_latents=image_latents,
+                                                    negative_prompt_embeds=negative_prompt_embeds)
         if not return_dict:
             return (latents,)
         return Step1XEditPipelineOutput(images=latents)

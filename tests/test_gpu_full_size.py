@@ -127,6 +127,54 @@ def test_bench_two_ranks_share_the_gpu(extra):
     assert abs(d["value"] - 28 * 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
 
 
+@pytest.mark.parametrize("extra", [[], ["--true-cfg", "6.0"]])
+def test_bench_eight_ranks_share_the_gpu(extra):
+    """BASELINE configs[3]'s launch shape without an 8-GPU node: EIGHT ranks (gloo, all on cuda:0,
+    toy trunk, 256 px) under torch.distributed.run exactly as the driver launches `--gpus 8`: per-rank K_e cycling
+    5 / 15 / 25 / 50 % twice, the 8-way gather of the final latents inside the timed region, the MAX-over-ranks clock, ONE
+    JSON line from rank 0 with 8 `per_rank` rows and value = 28 * steps * 8 / elapsed."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 30400 + (os.getpid() % 400) + (11 if extra else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "1", "--toy", "--size", "256",
+           "--share-gpu", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-vanilla"] + extra
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                               # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["unit"] == "steps/s" and d["steps"] == 1
+    pr = d["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(8))
+    assert [p["edit_frac"] for p in pr] == [0.05, 0.15, 0.25, 0.50] * 2
+    assert all(p["edit_s"] > 0 and p["K_e"] > 0 for p in pr)
+    assert [p["K_e"] for p in pr[:4]] == [p["K_e"] for p in pr[4:]] and pr[0]["K_e"] < pr[1]["K_e"] < pr[2]["K_e"] < pr[3]["K_e"]
+    assert ("true CFG 6.0" in d["config"]["workload"]) == bool(extra)
+    elapsed = d["ms_per_step"] * 1e-3 * d["steps"]
+    assert abs(d["value"] - 28 * d["steps"] * 8 / elapsed) < 1e-6 * d["value"]
+    assert elapsed >= max(p["edit_s"] for p in pr) * 0.999               # the job clock is the slowest rank's (plus the gather)
+
+
+def test_cfg_branch_pairs_world_four_share_the_gpu():
+    """`helper.shard_cfg_branches` at world 4 (two images, two (cond, uncond) rank pairs) with every rank on cuda:0 over gloo:
+    tools/cfg_shard_run.py checks on every rank that the sharded edit is bit-identical to the unsharded one and that the two
+    ranks of a pair hold the same latents (MIN-reduced over the world)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 30900 + (os.getpid() % 90)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "tools/cfg_shard_run.py", "--family", "qwen", "--toy", "--size", "256", "--share-gpu",
+           "--dist-backend", "gloo"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["world"] == 4 and d["shared_gpu"] and d["backend"] == "gloo"
+    assert d["sharded_bit_identical_to_unsharded"] and d["pair_ranks_agree"] and 0 < d["K_e"] < d["L"] == 256
+
+
 def test_bench_one_rank_executes_rccl_init_all_gather_and_max_reduce():
     """RCCL on hardware without a multi-GPU node: bench.py under torch.distributed.run with ONE rank, backend nccl (= RCCL on
     ROCm), `--force-collectives` -> process-group init on cuda:0, the barrier pair, the all_gather of the final latents inside

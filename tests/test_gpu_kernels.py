@@ -636,6 +636,36 @@ def test_gemm_fp8_weights_widened_once_bit_identical_to_fp8_tiles(M, N, K, epi, 
     assert torch.isfinite(outs[0].float()).all()
 
 
+def test_gemm_group_shared_fp8_weights_widened_once_per_matrix(monkeypatch):
+    """The widen-once A/B path (RGN_W8_WIDEN_MIN_M=1) on a four-problem group whose CFG branches share the stream's fp8 weight
+    matrix: the de-duplication branch of `widen_w8` (second user of a matrix points at the first one's widened copy) gives
+    the launch the fp8-tile path gives, bit for bit (advisor finding, round 3: the branch had no test)."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(23)
+    N, K = 3072, 3072
+    Ms = [1536, 1408, 512, 384]
+    As = [bf(torch.randn(m, K, generator=g)).cuda() for m in Ms]
+    W0 = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
+    W1 = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
+    b0, b1 = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+    Ws, bs = [W0, W0, W1, W1], [b0, b0, b1, b1]
+    gates = [bf(torch.randn(N, generator=g)).cuda() for _ in Ms]
+    res = [bf(torch.randn(m, N, generator=g)).cuda() for m in Ms]
+    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")          # whole-K tiles: the two paths' planners may cut remainders differently
+    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
+    outs = []
+    for widen in ("0", "1"):
+        monkeypatch.setenv("RGN_W8_WIDEN_MIN_M", widen)
+        xs = [r.clone() for r in res]
+        ops.gemm_group([ops.Problem(a, w, b, x, gate=gt, resid=x) for a, w, b, x, gt in zip(As, Ws, bs, xs, gates)],
+                       epilogue=ops.EPI_GATE_RESID)
+        torch.cuda.synchronize()
+        outs.append(xs)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) and torch.isfinite(a.float()).all()
+    assert not torch.equal(outs[0][0], res[0])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # round 3: up to four problems per launch (text / image stream x cond / uncond CFG branch), segmented LN-modulate
 # ---------------------------------------------------------------------------------------------------------------------

@@ -100,6 +100,20 @@ def test_step1x_stock_pipeline_call_shape_with_host_connector(v1p2):
     kw.update(output_type="pt", generator=_gen())
     img = pipe(**kw)
     assert tuple(img.images.shape) == (1, 3, 256, 256) and ("output_process", (256, 256)) in pipe.calls
+    think = dict(enable_thinking_mode=False, enable_reflection_mode=False)
+    if v1p2:
+        # the reference driver's own call, verbatim (src/Step1X-Edit-v1p2/main.py:42-43, :69-77): both switches False
+        c = pipe(image=_picture(), prompt="turn the sky green", num_inference_steps=28, true_cfg_scale=6.0, generator=_gen(),
+                 output_type="latent", **think).images
+        d = pipe(image=_picture(), prompt="turn the sky green", num_inference_steps=28, true_cfg_scale=6.0, generator=_gen(),
+                 output_type="latent", max_try_cnt=3).images
+        assert torch.equal(c, d) and torch.isfinite(c.float()).all()
+        for k in think:                                          # the VLM retry loop itself is not hosted: asked for -> loud
+            with pytest.raises(NotImplementedError, match=k):
+                pipe(image=_picture(), prompt="x", generator=_gen(), output_type="latent", **{k: True})
+    else:                                                        # v1p1's __call__ has no such arguments
+        with pytest.raises(TypeError, match="enable_thinking_mode"):
+            pipe(image=_picture(), prompt="x", generator=_gen(), output_type="latent", latents=None, **think)
     helper.disable()
     assert type(pipe) is cls
 
