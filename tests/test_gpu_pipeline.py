@@ -806,3 +806,26 @@ def test_cfg_branches_batched_through_one_pass_bit_identical_to_two_forwards(fam
     assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])), "a noise_pred of the batched pass differs from the two-forward run"
     assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
     assert torch.isfinite(a[1].float()).all()
+
+
+def test_attention_score_bound_is_loaded_eagerly_and_follows_in_place_weight_changes():
+    """Advisor finding (round 3): `Attention.score_bound()` - the caller-side guarantee the bounded softmax runs on - is computed for
+    every block when the weights are loaded (one device read for the trunk, none inside a forward) and is keyed on the norm
+    weights' (data_ptr, _version): an in-place change after first use (LoRA merge, .copy_) is seen, not silently violated."""
+    import math
+    cfg = synth.FluxConfig(**synth.TOY)
+    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=0.05)
+    tr = H.FluxTransformer2DModel(cfg, "cuda").load_state_dict(wts)
+    for blk in list(tr.transformer_blocks) + list(tr.single_transformer_blocks):
+        assert blk.attn.__dict__.get("_score_bound") is not None          # eager: nothing left for the first forward
+    a = tr.transformer_blocks[0].attn
+    b0 = a.score_bound()
+    wq = max(float(a.norm_q.float().abs().max()), float(a.norm_added_q.float().abs().max()))
+    wk = max(float(a.norm_k.float().abs().max()), float(a.norm_added_k.float().abs().max()))
+    assert b0 == pytest.approx(1.05 * a.head_dim * wq * wk / math.sqrt(a.head_dim), rel=1e-6)
+    assert a.score_bound() == b0
+    a.norm_k.mul_(3.0)                                                     # in place: same storage, new version
+    assert a.score_bound() == pytest.approx(3.0 * b0, rel=2e-2) or a.score_bound() > 1.5 * b0
+    s = tr.single_transformer_blocks[0].attn
+    s.norm_q = (s.norm_q * 2).contiguous()                                 # swapped tensor: new data_ptr
+    assert s.score_bound() > 1.5 * 1.05 * s.head_dim * 1.0 / math.sqrt(s.head_dim) * 0.5
