@@ -551,7 +551,28 @@ def main():
         result["full_token"] = {"edit_wall_clock_s": tv, "steps_per_s": N_STEPS / tv,
                                 "mfma_frac": N_STEPS * f_full / tv / 1e12 / PEAK_BF16_TFLOPS}
         result["speedup_vs_full_token"] = tv / edit_s
-        result["psnr_vs_full_token_db"] = O.psnr(out.cpu(), van.cpu())
+        # NOT the quality metric of BASELINE.json (PSNR >= 30.5 dB vs the full-token output): on N(0, 0.02^2) weights the trunk is no
+        # denoiser (no contraction towards an image), so this number only says the two loops ran on the same inputs; the
+        # measurable half of the target - agreement with the reference on identical inputs - is `parity` below
+        result["latent_psnr_vs_full_token_random_weights_db"] = {
+            "value": O.psnr(out.cpu(), van.cpu()),
+            "note": "random weights: not the quality metric (needs a real checkpoint; unmeasurable in this image)"}
+    if rank == 0 and world == 1:
+        # parity at the trunks' real depth (tools/parity_full_depth.py, tests/test_gpu_full_depth.py): the committed report
+        pf = os.path.join(ROOT, "profiles", "r04_parity_full_depth.json")
+        if os.path.exists(pf):
+            cases = {c["case"]: c for c in json.load(open(pf))["cases"]}
+            par = {"source": "profiles/r04_parity_full_depth.json (MI355X; hip vs oracle torch-CPU bf16)"}
+            for name, c in cases.items():
+                if "rows" in c:
+                    par[name] = {"min_psnr_db": min(r["psnr_hip_vs_oracle_db"] for r in c["rows"]), "blocks": c["blocks"], "d": c["d"],
+                                 "oracle_own_spread_min_psnr_db": min((r["psnr_oracle_reordered_vs_oracle_db"] for r in c["rows"]
+                                                                       if "psnr_oracle_reordered_vs_oracle_db" in r), default=None)}
+                else:
+                    par[name] = {"final_latents_psnr_db": c.get("psnr_final_db"), "ids_bit_exact": c.get("ids_bit_exact"),
+                                 "blocks": c["blocks"], "d": c["d"],
+                                 "oracle_own_spread_psnr_db": c.get("psnr_oracle_reordered_vs_oracle_db")}
+            result["parity_full_depth_db"] = par
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         plan = "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04))
         result["cpu_baseline"] = cpu_baseline(cfg, T, N, K_e, plan)

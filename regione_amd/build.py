@@ -18,11 +18,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-val
 EXTRA = {"region.hip": ["-ffp-contract=off"], "norm.hip": ["-ffp-contract=off"], "attn.hip": ["-fno-honor-nans"]}
 
 
+TORCH_LIB_PATH = os.path.join(LIB_DIR, "libregione_torch.so")
+TORCH_SRC = os.path.join(CSRC, "torch_binding.cpp")
+HEADER = os.path.join(HERE, "..", "include", "regione_hip.h")
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "regione_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".cpp")] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -57,5 +62,26 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     return LIB_PATH
 
 
+def build_torch_binding(force: bool = False, verbose: bool = True) -> str:
+    """csrc/torch_binding.cpp -> lib/libregione_torch.so: TORCH_LIBRARY(regione_mi) + the CUDA(HIP)-key kernels, host C++ only
+    (g++; the HIP code lives in libregione_hip.so, which this library links by $ORIGIN rpath).  ~10 s."""
+    build_lib(force=False, verbose=verbose)
+    deps = [TORCH_SRC, HEADER, LIB_PATH]
+    if not force and os.path.exists(TORCH_LIB_PATH) and all(os.path.getmtime(d) <= os.path.getmtime(TORCH_LIB_PATH) for d in deps):
+        return TORCH_LIB_PATH
+    import torch
+    troot = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", f"-I{troot}/include",
+           f"-I{troot}/include/torch/csrc/api/include", f"-I{rocm}/include", TORCH_SRC, "-o", TORCH_LIB_PATH, f"-L{troot}/lib",
+           "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", f"-L{LIB_DIR}", "-lregione_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return TORCH_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv))
+    print(build_torch_binding(force="--force" in sys.argv))

@@ -7,10 +7,20 @@ schemas with their mutation annotations (`Tensor(a!)`), and have fake (meta) imp
 The native boundary stays the C ABI of include/regione_hip.h; nothing here computes - every op forwards to
 the HIP library and raises if it is missing (no CPU fallback).
 
+Two registrations of the SAME schemas (`SCHEMAS` below), mutually exclusive in one process (same operator names):
+  * C++ (default when regione_amd/lib/libregione_torch.so is built): `TORCH_LIBRARY(regione_mi, m)` + `TORCH_LIBRARY_IMPL(regione_mi,
+    CUDA, m)` in csrc/torch_binding.cpp, linked against libregione_hip.so - `torch.ops.load_library(path)` alone makes
+    `torch.ops.regione_mi.*` resolve (C++ / AOT callers need no Python); this module then only adds the fake kernels;
+  * Python `torch.library` over the ctypes wrappers (`RGN_TORCH_OPS=py`; the A/B, and the fallback when the C++ library is absent).
+`RGN_TORCH_OPS=cpp` insists on the C++ registration (raises when the library is missing), `=0` sends the calls straight to
+`regione_amd.ops` (no dispatcher).
+
 This IS the surface the engine runs on: the family patch sets (`regione_amd/<Family>/inplace.py`, `utils.py`) and the
 attention processors (`harness/*.py`) call these ops through the dispatcher (`R = torch.ops.regione_mi`); only the
 [EXT] block bodies around them (LayerNorm-modulate, FeedForward / out-projection GEMMs) call `regione_amd.ops` directly.
-`RGN_TORCH_OPS=0` sends the same calls straight to `regione_amd.ops` (A/B for the dispatcher's host cost).
+fp8 weights: the per-output-channel scale rides on the weight tensor as a Python attribute (`ops.quantize_w8`), which a C++
+kernel cannot see - the projection ops therefore take it as an explicit optional argument (`w_scale`), and the engine-side
+accessor `R` fills it in from the attribute.
 
     import regione_amd.torch_ops            # registers the ops (idempotent)
     e, u, mask = torch.ops.regione_mi.arp_partition(sample, v, cond, dt_final, 0.88, 64, 64, True)
@@ -35,17 +45,34 @@ import torch
 
 from . import ops
 
+import os as _os
+
 NS = "regione_mi"
-_lib = torch.library.Library(NS, "FRAGMENT")   # (the dispatcher omits trailing arguments that equal their schema default:
-# every implementation below therefore repeats the defaults)
+CPP_LIB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "lib", "libregione_torch.so")
+_mode = _os.environ.get("RGN_TORCH_OPS", "")
+if _mode in ("", "1"):
+    _mode = "cpp" if _os.path.exists(CPP_LIB) else "py"
+if _mode == "cpp":
+    if not _os.path.exists(CPP_LIB):
+        raise ops._lib.RegionEHipError(f"RGN_TORCH_OPS=cpp but {CPP_LIB} is not built (python -m regione_amd.build)")
+    ops._lib.lib()                                  # libregione_hip.so first (the binding links against it by $ORIGIN rpath)
+    torch.ops.load_library(CPP_LIB)                 # TORCH_LIBRARY(regione_mi) + CUDA kernels: defined by the library itself
+    _lib = None
+else:
+    _lib = torch.library.Library(NS, "FRAGMENT")   # (the dispatcher omits trailing arguments that equal their schema default:
+    # every implementation below therefore repeats the defaults)
+REGISTRATION = {"cpp": "cpp", "py": "py"}.get(_mode, "py")      # which one this process holds ("0" still registers py)
 _defined = set()
+SCHEMAS = {}
 
 
 def _define(name: str, schema: str, impl, fake):
     if name in _defined:
         return
-    _lib.define(f"{name}{schema}")
-    torch.library.impl(_lib, name, "CUDA")(impl)
+    SCHEMAS[name] = schema
+    if _lib is not None:
+        _lib.define(f"{name}{schema}")
+        torch.library.impl(_lib, name, "CUDA")(impl)
     torch.library.register_fake(f"{NS}::{name}")(fake)
     _defined.add(name)
 
@@ -100,8 +127,16 @@ def _epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache,
                             eps=eps, fp16_roundtrip=fp16_roundtrip)
 
 
+def _scaled(w, w_scale):
+    """An fp8 weight whose scale arrived as an explicit argument (a caller without the Python attribute) gets it attached."""
+    if w_scale is not None and getattr(w, "_rgn_scale", None) is None:
+        w._rgn_scale = w_scale
+    return w
+
+
 def _kv_update(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base=0,
-               eps=1e-6, fp16_roundtrip=False, gelu_from_col=-1):
+               eps=1e-6, fp16_roundtrip=False, gelu_from_col=-1, w_scale=None):
+    w_kvq = _scaled(w_kvq, w_scale)
     epi = _epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip)
     ops.gemm_qkv(x, w_kvq, b_kvq, q_out, epi, gelu_from_col=3 * heads * 128 if gelu_from_col < 0 else gelu_from_col)
 
@@ -109,11 +144,13 @@ def _kv_update(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_
 _define("kv_partial_update_",
         "(Tensor x, Tensor w_kvq, Tensor? b_kvq, Tensor(a!) q_out, Tensor norm_q, Tensor norm_k, Tensor cos_q, Tensor sin_q, "
         "Tensor cos_k, Tensor sin_k, Tensor? kv_rows, Tensor(b!) k_cache, Tensor(c!) vt_cache, int heads, int row_base=0, "
-        "float eps=1e-6, bool fp16_roundtrip=False, int gelu_from_col=-1) -> ()", _kv_update, lambda *a, **k: None)
+        "float eps=1e-6, bool fp16_roundtrip=False, int gelu_from_col=-1, Tensor? w_scale=None) -> ()", _kv_update, lambda *a, **k: None)
 
 
 def _kv_update_pair(x_img, w_img, b_img, out_img, norm_q_img, norm_k_img, x_txt, w_txt, b_txt, out_txt, norm_q_txt, norm_k_txt,
-                    cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps=1e-6, fp16_roundtrip=False):
+                    cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps=1e-6, fp16_roundtrip=False,
+                    w_scale_img=None, w_scale_txt=None):
+    w_img, w_txt = _scaled(w_img, w_scale_img), _scaled(w_txt, w_scale_txt)
     e_img = _epi(norm_q_img, norm_k_img, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps, fp16_roundtrip)
     e_txt = _epi(norm_q_txt, norm_k_txt, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, 0, eps, False)
     ops.gemm_qkv_pair(x_img, w_img, b_img, out_img, e_img, x_txt, w_txt, b_txt, out_txt, e_txt)
@@ -125,12 +162,15 @@ _define("kv_partial_update_pair_",
         "(Tensor x_img, Tensor w_img, Tensor? b_img, Tensor(a!) out_img, Tensor norm_q_img, Tensor norm_k_img, "
         "Tensor x_txt, Tensor w_txt, Tensor? b_txt, Tensor(b!) out_txt, Tensor norm_q_txt, Tensor norm_k_txt, "
         "Tensor cos_q, Tensor sin_q, Tensor cos_k, Tensor sin_k, Tensor? kv_rows, Tensor(c!) k_cache, Tensor(d!) vt_cache, "
-        "int heads, int txt_len, float eps=1e-6, bool fp16_roundtrip=False) -> ()", _kv_update_pair, lambda *a, **k: None)
+        "int heads, int txt_len, float eps=1e-6, bool fp16_roundtrip=False, Tensor? w_scale_img=None, Tensor? w_scale_txt=None) -> ()",
+        _kv_update_pair, lambda *a, **k: None)
 
 
-def _kv_update_group(x, w, b, out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps=1e-6,
-                     fp16_roundtrip=(), gelu_from_col=-1):
+def _kv_update_group(x, w, w_scale, b, out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base,
+                     eps=1e-6, fp16_roundtrip=(), gelu_from_col=-1):
     rt = list(fp16_roundtrip) or [False] * len(x)
+    if len(w_scale):
+        w = [_scaled(wi, si) for wi, si in zip(w, w_scale)]
     probs = [ops.Problem(x[i], w[i], b[i], out[i],
                          epi=_epi(norm_q[i], norm_k[i], cos_q[i], sin_q[i], cos_k[i], sin_k[i], kv_rows[i], k_cache[i], vt_cache[i],
                                   heads, int(row_base[i]), eps, bool(rt[i]))) for i in range(len(x))]
@@ -140,9 +180,9 @@ def _kv_update_group(x, w, b, out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, k
 # the projections of up to four (stream, CFG branch) problems in ONE launch: per problem its activations, weights (shared
 # between the branches of a stream), RMSNorm weights, rotary tables, cache-row list and K / V^T cache (one per branch)
 _define("kv_partial_update_group_",
-        "(Tensor[] x, Tensor[] w_kvq, Tensor?[] b_kvq, Tensor(a!)[] q_out, Tensor[] norm_q, Tensor[] norm_k, Tensor[] cos_q, "
-        "Tensor[] sin_q, Tensor[] cos_k, Tensor[] sin_k, Tensor?[] kv_rows, Tensor(b!)[] k_cache, Tensor(c!)[] vt_cache, int heads, "
-        "int[] row_base, float eps=1e-6, bool[] fp16_roundtrip=[], int gelu_from_col=-1) -> ()", _kv_update_group,
+        "(Tensor[] x, Tensor[] w_kvq, Tensor?[] w_scale, Tensor?[] b_kvq, Tensor(a!)[] q_out, Tensor[] norm_q, Tensor[] norm_k, "
+        "Tensor[] cos_q, Tensor[] sin_q, Tensor[] cos_k, Tensor[] sin_k, Tensor?[] kv_rows, Tensor(b!)[] k_cache, Tensor(c!)[] vt_cache, "
+        "int heads, int[] row_base, float eps=1e-6, int[] fp16_roundtrip=[], int gelu_from_col=-1) -> ()", _kv_update_group,
         lambda *a, **k: None)
 
 
@@ -159,6 +199,40 @@ def registered() -> Tuple[str, ...]:
     return tuple(sorted(_defined))
 
 
+def _sc(w):
+    return ops._wscale(w)
+
+
+class _Dispatched:
+    """The engine-side accessor of the registered ops (`R.<op>(...)` = `torch.ops.regione_mi.<op>(...)`): identical for both
+    registrations; the three projection ops get the fp8 per-channel scale that rides on the weight tensor passed explicitly."""
+
+    def __getattr__(self, name):
+        return getattr(getattr(torch.ops, NS), name)
+
+    @staticmethod
+    def kv_partial_update_(x, w_kvq, *a, **kw):
+        s = _sc(w_kvq)
+        if s is not None:
+            kw["w_scale"] = s
+        return torch.ops.regione_mi.kv_partial_update_(x, w_kvq, *a, **kw)
+
+    @staticmethod
+    def kv_partial_update_pair_(x_img, w_img, b_img, out_img, nq_img, nk_img, x_txt, w_txt, *a, **kw):
+        s0, s1 = _sc(w_img), _sc(w_txt)
+        if s0 is not None or s1 is not None:
+            kw.update(w_scale_img=s0, w_scale_txt=s1)
+        return torch.ops.regione_mi.kv_partial_update_pair_(x_img, w_img, b_img, out_img, nq_img, nk_img, x_txt, w_txt, *a, **kw)
+
+    @staticmethod
+    def kv_partial_update_group_(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads,
+                                 row_base, eps=1e-6, fp16_roundtrip=(), gelu_from_col=-1):
+        sc = [_sc(w) for w in w_kvq]
+        return torch.ops.regione_mi.kv_partial_update_group_(
+            x, w_kvq, sc if any(s is not None for s in sc) else [], b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows,
+            k_cache, vt_cache, heads, row_base, eps, [int(bool(f)) for f in fp16_roundtrip], gelu_from_col)
+
+
 class _Direct:
     """`RGN_TORCH_OPS=0`: the same names bound straight to regione_amd.ops (no dispatcher) - A/B switch only."""
     arp_partition = staticmethod(_arp)
@@ -169,9 +243,11 @@ class _Direct:
     cfg_combine = staticmethod(ops.cfg_combine)
     kv_partial_update_ = staticmethod(_kv_update)
     kv_partial_update_pair_ = staticmethod(_kv_update_pair)
-    kv_partial_update_group_ = staticmethod(_kv_update_group)
     region_attention = staticmethod(_region_attention)
 
+    @staticmethod
+    def kv_partial_update_group_(x, w_kvq, b_kvq, *a, **kw):
+        return _kv_update_group(x, w_kvq, [], b_kvq, *a, **kw)
 
-import os as _os
-R = _Direct if _os.environ.get("RGN_TORCH_OPS", "1") == "0" else getattr(torch.ops, NS)
+
+R = _Direct if _mode == "0" else _Dispatched()

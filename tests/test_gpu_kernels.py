@@ -1008,3 +1008,58 @@ def test_attention_with_a_caller_guaranteed_score_bound_needs_no_running_max(Sq,
     assert rel_err(outs["static"], outs["tracked"].double()) < 5e-3
     if w == 2.5:
         assert torch.equal(outs["static"], outs["tracked"])              # bound too large: the running max is kept
+
+
+@pytest.mark.parametrize("variant", ["4", "8"])
+def test_attention_static_shift_at_the_ends_of_its_dynamic_range(variant, monkeypatch):
+    """The rows the bounded softmax is argued safe for (attn.hip: static_m = 0, P = exp2(s * log2 e) within 2^+-96), which random
+    draws never produce: with bound * log2(e) = 95.9, (i) a query ALIGNED with one key (s = +bound) and
+    ANTI-ALIGNED with another (s = -bound) in the same row - P spans 2^+95.9 ... 2^-95.9 in one row sum; (ii) the mirrored query;
+    (iii) a head in which EVERY score is -bound (all keys identical, queries opposite): every P is 2^-95.9, the row sum
+    1024 * 2^-95.9 must not vanish and the output is the plain mean of V.  Checked against the fp32 softmax and against the
+    tracked-max kernel; all finite."""
+    from regione_amd import ops
+    monkeypatch.setenv("RGN_ATTN_VARIANT", variant)          # 8 = the 8-wave hand-scheduled kernel the pipeline runs, 4 = tiny query sets
+    g = torch.Generator().manual_seed(5)
+    Sq, Skv, H = 256, 1024, 2
+    D = H * 128
+    bound = 95.9 / 1.4426950408889634                     # |s| <= bound  <=>  |s * log2 e| <= 95.9 (static shift engaged: <= 96)
+    c = math.sqrt(bound * math.sqrt(128.0) / 128.0)       # q = k = c * u, u_i = +-1:  q . k / sqrt(128) = c^2 * 128 / sqrt(128)
+    u = torch.where(torch.rand(128, generator=g) < 0.5, -1.0, 1.0)
+    q = torch.randn(Sq, H, 128, generator=g) * 0.3
+    k = torch.randn(Skv, H, 128, generator=g) * 0.3
+    v = torch.randn(Skv, H, 128, generator=g)
+    q[0, 0], q[1, 0] = c * u, -c * u                      # head 0: rows 0 / 1 against keys 0 / 1
+    k[0, 0], k[1, 0] = c * u, -c * u
+    q[:, 1] = -c * u                                      # head 1: every score = -bound
+    k[:, 1] = c * u
+    q, k, v = bf(q.reshape(Sq, D)), bf(k.reshape(Skv, D)), bf(v.reshape(Skv, D))
+    qq, kk, vv = (t.float().view(-1, H, 128).transpose(0, 1) for t in (q, k, v))
+    s = torch.einsum("hqd,hkd->hqk", qq, kk) / math.sqrt(128.0)
+    assert float(s.abs().max()) <= bound and float(s[0, 0, 0]) > 0.99 * bound and float(s[0, 0, 1]) < -0.99 * bound
+    assert float(s[1].max()) < -0.99 * bound
+    pad = ops.padded(Skv)
+    ks = torch.zeros(pad, D, dtype=torch.bfloat16)
+    ks[:Skv] = k
+    r = torch.arange(Skv)
+    pos = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1)
+    vt = torch.zeros(D, pad, dtype=torch.bfloat16)
+    vt[:, pos] = v.T
+    outs = {}
+    for name, env in (("static", None), ("tracked", "0")):
+        if env is None:
+            monkeypatch.delenv("RGN_ATTN_STATIC_MAX", raising=False)
+        else:
+            monkeypatch.setenv("RGN_ATTN_STATIC_MAX", env)
+        o = torch.empty(Sq, D, dtype=torch.bfloat16).cuda()
+        ops.attention(q.cuda(), ks.cuda(), vt.cuda(), o, Skv, H, score_bound=bound)
+        torch.cuda.synchronize()
+        outs[name] = o.cpu()
+    ref = torch.einsum("hqk,hkd->hqd", torch.softmax(s.double(), -1), vv.double()).transpose(0, 1).reshape(Sq, D)
+    for name, o in outs.items():
+        assert torch.isfinite(o.float()).all(), name
+        assert rel_err(o, ref) < 1e-2, (name, rel_err(o, ref))
+        # the two crafted rows pick out ONE value row each; the all-negative head returns the mean of V
+        assert rel_err(o[0, :128], vv[0, 0].double()) < 1e-2 and rel_err(o[1, :128], vv[0, 1].double()) < 1e-2, name
+        assert rel_err(o[:, 128:], vv[1].double().mean(0).expand(Sq, 128)) < 2e-2, name
+    assert rel_err(outs["static"], outs["tracked"].double()) < 5e-3

@@ -1,9 +1,69 @@
-"""`torch.ops.regione_mi.*` (regione_amd/torch_ops.py): dispatcher-visible registration of the hot-path ops.
-CPU: schemas / mutation annotations / fake kernels (no compute).  GPU: each op equals the ctypes wrapper."""
+"""`torch.ops.regione_mi.*`: dispatcher-visible registration of the hot-path ops - in C++ (csrc/torch_binding.cpp,
+TORCH_LIBRARY(regione_mi); the default) and through Python torch.library (regione_amd/torch_ops.py, RGN_TORCH_OPS=py).
+CPU: schemas / mutation annotations / fake kernels (no compute).  GPU: each op equals the ctypes wrapper.
+The whole module is re-run in a subprocess on the OTHER registration (`..._on_the_other_registration`), and the C++ library
+is loaded with `torch.ops.load_library` alone (no regione_amd import) to show that the ops exist without the Python shim."""
+import json
+import os
+import subprocess
+import sys
+
 import pytest
 import torch
 
 import regione_amd.torch_ops as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OTHER = {"cpp": "py", "py": "cpp"}[T.REGISTRATION]
+NESTED = os.environ.get("RGN_TORCH_OPS_NESTED") == "1"
+
+
+def _rerun(marker):
+    env = dict(os.environ, RGN_TORCH_OPS=OTHER, RGN_TORCH_OPS_NESTED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", marker, "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and f"registration={OTHER}" in r.stdout
+
+
+def test_which_registration(capsys):
+    assert T.REGISTRATION in ("cpp", "py")
+    with capsys.disabled():
+        print(f" registration={T.REGISTRATION} ", end="")
+    if T.REGISTRATION == "cpp":
+        assert os.path.exists(T.CPP_LIB)
+
+
+@pytest.mark.skipif(NESTED, reason="already the re-run")
+def test_cpu_part_passes_on_the_other_registration():
+    _rerun("not gpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NESTED, reason="already the re-run")
+def test_gpu_part_passes_on_the_other_registration():
+    _rerun("gpu")
+
+
+@pytest.mark.skipif(NESTED, reason="already the re-run")
+def test_cpp_library_alone_defines_the_ops_with_the_python_registrations_schemas():
+    """`torch.ops.load_library(libregione_torch.so)` with NOTHING of regione_amd imported: every op resolves, and its schema is
+    character for character the one the Python registration defines from `torch_ops.SCHEMAS`."""
+    code = ("import json, sys, torch; torch.ops.load_library(sys.argv[1]); "
+            "names = sys.argv[2].split(','); "
+            "assert 'regione_amd' not in sys.modules; "
+            "print(json.dumps({n: str(getattr(torch.ops.regione_mi, n).default._schema) for n in names}))")
+    names = sorted(T.SCHEMAS)
+    r = subprocess.run([sys.executable, "-c", code, T.CPP_LIB, ",".join(names)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    cpp = json.loads(r.stdout.strip().splitlines()[-1])
+    code = ("import json, torch, regione_amd.torch_ops as T; assert T.REGISTRATION == 'py'; "
+            "print(json.dumps({n: str(getattr(torch.ops.regione_mi, n).default._schema) for n in T.SCHEMAS}))")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, RGN_TORCH_OPS="py"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    py = json.loads(r.stdout.strip().splitlines()[-1])
+    assert cpp == py and len(cpp) == 10
 
 
 def test_ops_are_registered_with_schemas():

@@ -139,7 +139,7 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
                plan=kinds, plan_matches_reference_logic=(kinds == plan), ids_match_constructed_region=bool(torch.equal(ids, want)),
                finite=bool(torch.isfinite(out.float()).all()), steps=steps, regione_edit_s=tr_s, regione_steps_per_s=steps / tr_s,
                full_token_edit_s=tv, full_token_steps_per_s=steps / tv, speedup=tv / tr_s,
-               psnr_vs_full_token_db=float(O.psnr(out.cpu(), van.cpu())), cfg_scale=cfg_scale,
+               latent_psnr_vs_full_token_random_weights_db=float(O.psnr(out.cpu(), van.cpu())), cfg_scale=cfg_scale,
                peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, weights="fp8 e4m3fn + per-channel scale" if fp8 else "bf16")
     # GPU time per denoising step by kind (an event at every callback_on_step_end), and - RGN_CFG_KTIMER=1 - the per-shape
     # launch table of one more edit (HIP events around every GEMM / attention launch, like bench.py)
@@ -167,10 +167,26 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
         kt.unwrap()
         res["kernels"] = {k: {kk: (round(vv, 2) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in kt.summary().items()}
         res["gemm_shapes"] = kt.shape_table(16)
+    # what the footprint is made of (hard part 3: the RIKV cache is 6.0 GB per CFG branch for FLUX at 1024^2)
+    slab = lambda t: t.numel() * t.element_size()
+    rikv = {}
+    tr = pipe.transformer
+    for blk in list(tr.transformer_blocks) + list(tr.single_transformer_blocks):
+        for tag, (k_slab, vt_slab, _skv) in getattr(blk.attn.processor, "caches", {}).items():
+            rikv[str(tag)] = rikv.get(str(tag), 0) + slab(k_slab) + slab(vt_slab)
+    res["rikv_cache_gb_by_branch"] = {k: round(v / 2 ** 30, 3) for k, v in rikv.items()}
+    res["rikv_cache_gb"] = round(sum(rikv.values()) / 2 ** 30, 3)
+    res["allocated_after_edit_gb"] = round(torch.cuda.memory_allocated() / 2 ** 30, 3)
     helper.disable()
+    # the injection closure (scheduler.step -> pipe) and the patched hooks form reference cycles: without a collection the
+    # previous case's 24-41 GB trunk stays allocated into the next case and `peak_mem_gb` accumulates
+    tr = blk = None
     del pipe, helper
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
+    res["allocated_after_release_gb"] = round(torch.cuda.memory_allocated() / 2 ** 30, 3)
     return res
 
 
