@@ -484,6 +484,55 @@ def test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled(
     assert rel_err(fix[0].cpu(), whole.cpu()) < 2e-3
 
 
+@pytest.mark.parametrize("nsplit", [2, 3, 6])
+@pytest.mark.parametrize("case", ["gate", "bias_ragged", "gelu", "fp8_gate", "group4_gate", "scatter"])
+def test_gemm_split_k_fine_reduce_bit_identical_to_tile_reduce(case, nsplit, monkeypatch):
+    """Round 4: the reduce pass of a split-K remainder as 8 workgroups per tile with the epilogue in registers
+    (gemm_reduce4w_kernel) against the one-workgroup-per-tile pass (RGN_GEMM_FINE_REDUCE=0): same summation order, same epilogue
+    expressions -> torch.equal, for every epilogue it serves, ragged M / N edges, fp8 weights (channel scale on the fp32 sum),
+    a four-problem group with per-problem gates and the row-scatter form."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(len(case) * 7 + nsplit)
+    K = 6144
+    N = {"bias_ragged": 712, "gelu": 1024}.get(case, 3072)
+    Ms = [1024, 1000, 512, 300] if case == "group4_gate" else [777]
+    As = [bf(torch.randn(m, K, generator=g)).cuda() for m in Ms]
+    W0 = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    W1 = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    if case == "fp8_gate":
+        W0 = ops.quantize_w8(W0)
+    Ws = [W0, W0, W1, W1][:len(Ms)]
+    b = bf(torch.randn(N, generator=g)).cuda()
+    gates = [bf(torch.randn(N, generator=g)).cuda() for _ in Ms]
+    xs = [bf(torch.randn(m, N, generator=g)).cuda() for m in Ms]
+    rows = torch.randperm(1500, generator=g)[:Ms[0]].cuda() if case == "scatter" else None
+    big = bf(torch.randn(1500, N, generator=g)).cuda() if case == "scatter" else None
+    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
+    monkeypatch.setenv("RGN_GEMM_NSPLIT", str(nsplit))
+
+    def run():
+        outs = [x.clone() for x in xs]
+        if case == "scatter":
+            o = big.clone()
+            ops.gemm(As[0], Ws[0], b, o, out_rows=rows)
+            outs = [o]
+        elif case.endswith("gate"):
+            ops.gemm_group([ops.Problem(a, w, b, o, gate=gt, resid=o) for a, w, o, gt in zip(As, Ws, outs, gates)], epilogue=ops.EPI_GATE_RESID)
+        elif case == "gelu":
+            ops.gemm(As[0], Ws[0], b, outs[0], epilogue=ops.EPI_GELU, gelu_from_col=512)
+        else:
+            ops.gemm(As[0], Ws[0], b, outs[0])
+        torch.cuda.synchronize()
+        assert ops._lib.lib().rgn_gemm_last_plan() & 255 == nsplit
+        return torch.cat(outs)
+    monkeypatch.setenv("RGN_GEMM_FINE_REDUCE", "1")
+    fine = run()
+    monkeypatch.setenv("RGN_GEMM_FINE_REDUCE", "0")
+    tile = run()
+    assert torch.equal(fine, tile), float((fine.float() - tile.float()).abs().max())
+    assert torch.isfinite(fine.float()).all()
+
+
 @pytest.mark.parametrize("asmv", ["0", "1"])
 @pytest.mark.parametrize("M,N,K,epi", [(8704, 3072, 3072, "bias"), (1536, 21504, 3072, "gelu"), (700, 3072, 15360, "gate"),
                                        (513, 520, 128, "bias"), (8192, 512, 192, "gelu"), (300, 704, 256, "gate"),
