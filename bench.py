@@ -195,6 +195,8 @@ def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "regione_amd", "csrc")
     for f in sorted(os.listdir(d)):
+        if not f.endswith((".hip", ".inc", ".h")):          # kernel sources only (the torch binding is host C++)
+            continue
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -490,19 +492,28 @@ def main():
     # PMC passes cannot run inside the timed region (counter collection serialises kernels): the per-launch HBM-side
     # traffic comes from a separate rocprofv3 --pmc run of THIS command (tools/pmc_traffic.py -> profiles/r03_pmc_traffic.json),
     # quoted only when that file was measured on the same kernel sources (csrc_sha16); otherwise null
-    pmc, pmc_file = {}, "profiles/r03_pmc_traffic.json"
+    pmc, pmc_file = {}, "profiles/r04_pmc_traffic.json"
+    busy, busy_file = {}, "profiles/r04_pmc_mfma.json"       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel family
     try:
         pmc = json.load(open(os.path.join(ROOT, pmc_file)))
         if pmc.get("csrc_sha16") != csrc_hash():
             pmc = {}
     except (OSError, ValueError):
         pmc = {}
+    try:
+        busy = json.load(open(os.path.join(ROOT, busy_file)))
+        if busy.get("csrc_sha16") != csrc_hash():
+            busy = {}
+    except (OSError, ValueError):
+        busy = {}
     if "gemm_bf16_kernel" in ksum:
         k = ksum["gemm_bf16_kernel"]
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": k["achieved_tflops"],
                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
                               "traffic": pmc.get("gemm_bf16_kernel", {}).get("traffic_bytes_per_launch"),
                               "traffic_unit": f"bytes/launch (L2<-fabric reads x2-corrected + WRITE_SIZE, {pmc_file}, same csrc_sha16)",
+                              "mfma_busy": busy.get("ALL gemm_bf16_kernel", {}).get("mfma_util"),
+                              "mfma_busy_unit": f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), {busy_file}, same csrc_sha16",
                               "launches": k["launches"], "avg_launch_us": k["avg_us"],
                               "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
     result["gemm_shapes"] = timer.shape_table()
@@ -511,6 +522,7 @@ def main():
         result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_asm_kernel (+ attention_kernel for ragged KV lengths)", "achieved": k["achieved_tflops"],
                                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
                                         "traffic": pmc.get("attention_kernel", {}).get("traffic_bytes_per_launch"),
+                                        "mfma_busy": busy.get("ALL attention_kernel", {}).get("mfma_util"),
                                         "launches": k["launches"], "avg_launch_us": k["avg_us"],
                                         "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
 

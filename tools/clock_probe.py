@@ -15,8 +15,65 @@ def smi():
     return (sclk and sclk.group(1), mclk and mclk.group(1), pw and pw.group(1))
 
 
+def edit_probe(n_edits=6):
+    """The whole 28-step RegionE edit (bench.py's workload) under the poller: what the board draws and clocks at in the pipeline the
+    metric is measured on.  Returns the record main() prints as JSON."""
+    import contextlib, threading
+    import bench as B
+    from regione_amd import RegionEHelper, synth
+    dev = torch.device("cuda", 0)
+    cfg = synth.FluxConfig()
+    pipe = B.build_pipeline(cfg, dev, seed=42)
+    h = w = 64
+    lat, img, prompt, pooled = [t.to(dev) for t in synth.make_edit_inputs(h, w, 512, cfg, seed=110, dtype=torch.bfloat16)]
+    helper = RegionEHelper(pipe)
+    with contextlib.redirect_stdout(sys.stderr):
+        helper.set_params(threshold=0.88, cache_threshold=0.04)
+    helper.enable()
+    B.install_region_injection(pipe, h, w, (17, 47, 17, 47), img[0:1], seed=7)
+    run = lambda: pipe(image=img, prompt_embeds=prompt, pooled_prompt_embeds=pooled, height=1024, width=1024, latents=lat,
+                       guidance_scale=2.5, return_dict=False)
+    run(); torch.cuda.synchronize()
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            samples.append(smi())
+    th = threading.Thread(target=poll)
+    t0 = time.time()
+    th.start()
+    for _ in range(n_edits):
+        run()
+    torch.cuda.synchronize()
+    el = (time.time() - t0) / n_edits
+    stop.set(); th.join()
+    f_full, f_reg = B.algorithmic_flops(cfg, 512, 8192, int(pipe._regione_manager.edited_ids.shape[1]))
+    return samples, el, 9 * f_full + 5 * f_reg             # plan FFFFFFRCRCCRCRCFCCCCCCCRCCFF: 9 full + 5 region + 14 cache-served steps
+
+
+def summarise(what, samples, us_per_launch, flops_per_launch):
+    ws = [float(p) for _, _, p in samples if p]
+    cl = [float(c) for c, _, _ in samples if c]
+    ws, cl = ws[len(ws) // 5:], cl[len(cl) // 5:]                  # drop the ramp
+    rec = dict(kernel=what, samples=len(ws), power_w_mean=sum(ws) / max(len(ws), 1), power_w_max=max(ws, default=0.0),
+               sclk_mhz_mean=sum(cl) / max(len(cl), 1), sclk_mhz_min=min(cl, default=0.0), us_per_launch=us_per_launch)
+    if flops_per_launch and us_per_launch:
+        tf = flops_per_launch / us_per_launch / 1e6
+        rec.update(tflops=tf, pj_per_flop=rec["power_w_mean"] / (tf * 1e12) * 1e12 if tf else None,
+                   tflops_per_ghz=tf / (rec["sclk_mhz_mean"] / 1e3) if rec["sclk_mhz_mean"] else None,
+                   dense_bf16_peak_at_this_clock_tflops=2500.0 * rec["sclk_mhz_mean"] / 2400.0)
+    return rec
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "attn"
+    as_json = "--json" in sys.argv
+    if what == "edit":
+        samples, el, fl = edit_probe()
+        rec = summarise("28-step RegionE edit (FLUX 1024^2, K_e 25 %)", samples, el * 1e6, fl)
+        import json
+        print(json.dumps(rec))
+        return
     rnd = lambda *s: (torch.rand(*s, device="cuda") * 2 - 1).to(torch.bfloat16)
     if what == "attn":
         H, S = 24, 8704
@@ -41,11 +98,20 @@ def main():
         fn()
     e.record()
     t0 = time.time()
+    samples = []
     while not e.query() and time.time() - t0 < 20:
-        print(f"t={time.time()-t0:5.2f}s sclk/mclk/W:", smi(), flush=True)
+        samples.append(smi())
+        if not as_json:
+            print(f"t={time.time()-t0:5.2f}s sclk/mclk/W:", samples[-1], flush=True)
     torch.cuda.synchronize()
     if n:
-        print(f"{what}: {s.elapsed_time(e)/n*1e3:.1f} us per launch sustained over {n} launches")
+        us = s.elapsed_time(e) / n * 1e3
+        flops = {"attn": 4.0 * 8704 * 8704 * 3072, "gemm": 2.0 * 8704 * 21504 * 3072, "vendor": 2.0 * 8704 * 21504 * 3072}.get(what)
+        if as_json:
+            import json
+            print(json.dumps(summarise(what, samples, us, flops)))
+        else:
+            print(f"{what}: {us:.1f} us per launch sustained over {n} launches")
 
 
 if __name__ == "__main__":

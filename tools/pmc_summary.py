@@ -32,7 +32,7 @@ def main():
     # one row per (dispatch, counter): the counter's instances (XCC / SE dimensions) summed, and how many there were
     agg = {}
     for name, _, counter, rows, total in c.execute(q):
-        if "gemm_bf16_kernel" in name or "attention_kernel" in name or "attention_asm_kernel" in name:
+        if "gemm_bf16_kernel" in name or "gemm_reduce4w_kernel" in name or "attention_kernel" in name or "attention_asm_kernel" in name:
             short = name.split("(")[0].replace("void rgn::", "")
             for k in (short, "ALL " + ("gemm_bf16_kernel" if "gemm" in name else "attention_kernel")):
                 d = agg.setdefault(k, {}).setdefault(counter, [0, 0.0, 0])
@@ -54,6 +54,9 @@ def main():
     out["note"] = ("one rocprofv3 --kernel-trace --pmc pass over `bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-vanilla`; "
                    "mfma_util = sum over instances of SQ_VALU_MFMA_BUSY_CYCLES / (mean GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs) (gfx94x derived-metric formula); kernels are "
                    "slowed by the counter collection, ratios are what to read")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash
+    out["csrc_sha16"] = csrc_hash()           # bench.py quotes mfma_busy only for a build of the same kernel sources
     json.dump(out, sys.stdout, indent=1)
 
 

@@ -31,13 +31,45 @@ def per_kernel(db):
     for name, counter, n, total in c.execute(q):
         # attention_asm_kernel (hand-scheduled loop) and attention_kernel (ragged KV lengths) count as one kernel family;
         # the small merge kernels (attention_combine*) are left out
-        k = ("gemm_bf16_kernel" if "gemm_bf16_kernel" in name else
+        k = ("gemm_bf16_kernel" if ("gemm_bf16_kernel" in name or "gemm_reduce4w_kernel" in name) else
              "attention_kernel" if ("attention_kernel" in name or "attention_asm_kernel" in name) else None)
         if k:
             d = out.setdefault(k, {}).setdefault(counter, [0, 0.0])
             d[0] += n
             d[1] += total
     return out
+
+
+def by_grid(db, top=14):
+    """Read bytes (x2-corrected) per dispatch grouped by (kernel template, grid size): the grid identifies the projection (tiles of
+    the launch), so the fabric traffic of ONE shape can be set against its operand bytes."""
+    c = sqlite3.connect(db)
+    ev, info, disp, sym = (table(c, "rocpd_pmc_event"), table(c, "rocpd_info_pmc"), table(c, "rocpd_kernel_dispatch"),
+                           table(c, "rocpd_info_kernel_symbol"))
+    dcols = [r[1] for r in c.execute(f"pragma table_info({disp})")]
+    gx, wx = ("grid_size_x", "workgroup_size_x") if "grid_size_x" in dcols else (None, None)
+    if gx is None:
+        return []
+    cols = [r[1] for r in c.execute(f"pragma table_info({ev})")]
+    key = "event_id" if "event_id" in cols else "dispatch_id"
+    dkey = "event_id" if key == "event_id" else "id"
+    q = (f"select s.kernel_name, d.{gx} / d.{wx}, p.name, count(distinct d.id), sum(e.value) from {ev} e join {info} p on e.pmc_id = p.id "
+         f"join {disp} d on e.{key} = d.{dkey} join {sym} s on d.kernel_id = s.id group by s.kernel_name, d.{gx} / d.{wx}, p.name")
+    acc = {}
+    for name, blocks, counter, n, total in c.execute(q):
+        if "gemm" not in name and "attention" not in name:
+            continue
+        short = name.split("(")[0].replace("void rgn::", "")
+        d = acc.setdefault((short, int(blocks)), {"n": n})
+        d[counter] = total
+    rows = []
+    for (short, blocks), d in acc.items():
+        if "TCC_EA0_RDREQ_sum" not in d:
+            continue
+        req, r32 = d["TCC_EA0_RDREQ_sum"], d.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        rows.append(dict(kernel=short, workgroups=blocks, dispatches=d["n"], read_bytes_x2_per_launch=2 * ((req - r32) * 64 + r32 * 32) / d["n"]))
+    rows.sort(key=lambda r: -r["read_bytes_x2_per_launch"] * r["dispatches"])
+    return rows[:top]
 
 
 def main():
@@ -53,6 +85,10 @@ def main():
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import csrc_hash
+    try:
+        res["reads_by_kernel_and_grid"] = by_grid(sys.argv[1])
+    except sqlite3.Error as e:                # schema differences between rocprofv3 versions: the totals above do not depend on it
+        res["reads_by_kernel_and_grid"] = f"unavailable: {e}"
     res["csrc_sha16"] = csrc_hash()          # bench.py quotes this file only for a build of the same kernel sources
     res["note"] = ("rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum (own pass) and --pmc WRITE_SIZE (own pass) over "
          "`bench.py --steps 1 --warmup 0`; read bytes = ((RDREQ-RDREQ_32B)*64 + RDREQ_32B*32), doubled per MI355X_MICROARCH.md "
