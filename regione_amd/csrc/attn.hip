@@ -468,9 +468,6 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
         const size_t slot = SPLIT == 2 ? (size_t)unit * 2 + seg : (size_t)(item - g.item_offset) * g.nsplit + split;
         float* base = g.ws + slot * (size_t)(QB * 130);
         float* orow = base + (size_t)(wave * 32 + ql) * 128;
-#ifdef RGN_ATTN_ABL_NODUMP                    /* timing-only ablation build (tools/probes): results are garbage */
-        if (g.Sq < 0)
-#endif
         static_for<16>([&](auto Ic) {
             constexpr int I = decltype(Ic)::value;           // I = db * 4 + r4
             constexpr int db = I / 4, r4 = I % 4;
