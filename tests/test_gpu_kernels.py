@@ -2,6 +2,7 @@
 Floating point: tolerances are stated per test; bf16 outputs are compared after the same rounding
 points as the eager bf16 sequence, so most results agree to <= 1 bf16 ulp."""
 import math
+import os
 
 import pytest
 import torch
@@ -1112,3 +1113,34 @@ def test_attention_static_shift_at_the_ends_of_its_dynamic_range(variant, monkey
         assert rel_err(o[0, :128], vv[0, 0].double()) < 1e-2 and rel_err(o[1, :128], vv[0, 1].double()) < 1e-2, name
         assert rel_err(o[:, 128:], vv[1].double().mean(0).expand(Sq, 128)) < 2e-2, name
     assert rel_err(outs["static"], outs["tracked"].double()) < 5e-3
+
+
+@pytest.mark.parametrize("Ms,N,K", [((1137,), 3072, 15360), ((625, 512), 3072, 12288), ((1056,), 3072, 15360), ((448, 512), 3072, 12288)])
+def test_gemm_planner_long_k_region_shapes_take_the_256_geometry_with_split_k(Ms, N, K):
+    """Round 4 (tools/probes/plan_sweep.py --dense): FLUX proj_out / FF-down at K_e 8 ... 18 % are 48 ... 60 tiles of 256 x 256 with
+    K = 12288 / 15360.  The round-3 cost model priced the 128 x 128 geometry (and the quarter-tile remainder built on it) at its
+    one-block-per-CU rate although 190+ blocks are co-located two per CU, and took it: 212 us where 256 x 256 + split-K runs in 117.
+    The planner must now pick the 256 geometry with 3 ... 5 K pieces for them (rgn_gemm_last_plan: bit 10 = 256 geometry, bits 0-7 =
+    pieces, bit 8 = quarter), and the result equals the unsplit launch to rounding."""
+    from regione_amd import ops
+    g = torch.Generator().manual_seed(sum(Ms) + K)
+    As = [bf(torch.randn(m, K, generator=g)).cuda() for m in Ms]
+    Ws = [bf(torch.randn(N, K, generator=g) * 0.05).cuda() for _ in Ms]
+    b, gate = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
+    xs = [bf(torch.randn(m, N, generator=g)).cuda() for m in Ms]
+
+    def run():
+        outs = [x.clone() for x in xs]
+        ops.gemm_group([ops.Problem(a, w, b, o, gate=gate, resid=o) for a, w, o in zip(As, Ws, outs)], epilogue=ops.EPI_GATE_RESID)
+        torch.cuda.synchronize()
+        return torch.cat(outs), ops._lib.lib().rgn_gemm_last_plan()
+    out, plan = run()
+    assert plan & (1 << 10), f"plan {plan:#x}: 128 geometry"
+    assert not plan & (1 << 8), f"plan {plan:#x}: quarter-tile remainder"
+    assert 3 <= (plan & 255) <= 5, plan & 255
+    os.environ["RGN_GEMM_SPLIT"] = "0"
+    try:
+        whole, _ = run()
+    finally:
+        del os.environ["RGN_GEMM_SPLIT"]
+    assert rel_err(out.cpu(), whole.cpu()) < 2e-3

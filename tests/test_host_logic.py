@@ -399,3 +399,42 @@ def test_scheduler_config_keys_honoured_or_refused():
     for bad in (dict(use_karras_sigmas=True), dict(stochastic_sampling=True), dict(some_new_key=1), dict(time_shift_type="cubic")):
         with pytest.raises(ValueError):
             H.FlowMatchEulerDiscreteScheduler(**bad)
+
+
+def test_reversed_k_oracle_is_the_same_arithmetic_in_another_summation_order():
+    """tools/parity_full_depth.py's yardstick (the oracle with every Linear summed in the opposite order along K): on the toy trunk
+    the two oracle runs agree to fp32 summation noise in fp32 and to bf16 rounding in bf16, differ bit-wise somewhere, and the
+    context manager puts the oracle's own `_lin` back."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_full_depth as P
+    from oracle import regione_oracle as O
+    from regione_amd import synth
+    cfg = synth.FluxConfig(**synth.TOY)
+    h = w = 8
+    T = 16
+    orig = O._lin
+    outs = {}
+    for dt in (torch.float32, torch.bfloat16):
+        wts = synth.make_flux_weights(cfg, seed=3, dtype=dt, w_std=0.05)
+        lat, img, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=4, dtype=dt)
+        ids = synth.flux_latent_ids(h, w)
+
+        def fwd():
+            st = O.RegionState()
+            st.set_parameters(28, 6, 2, "16", 0.5, 0.04, True)
+            st.refresh(img, ids, T, h, w)
+            with torch.no_grad():
+                return O.transformer_forward(wts, O.FluxCfg(**synth.TOY), st, [O.KVCache() for _ in range(cfg.n_layers)],
+                                             torch.cat([lat, img], 1), prompt, pooled, torch.full([1], 0.5, dtype=dt), ids,
+                                             torch.zeros(T, 3), torch.full([1], 2.5))
+        a = fwd()
+        with P.reversed_k_linears():
+            assert O._lin is not orig
+            b = fwd()
+        assert O._lin is orig
+        outs[dt] = (a, b)
+    a, b = outs[torch.float32]
+    assert not torch.equal(a, b) and float((a - b).abs().max() / a.abs().max()) < 1e-4
+    a, b = outs[torch.bfloat16]
+    assert O.psnr(b, a) > 40.0
