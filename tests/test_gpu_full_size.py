@@ -214,7 +214,11 @@ def test_bench_json_contract_single_gpu():
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert "traffic" in rf
+    assert "traffic" in rf and "mfma_busy" in rf
+    # every MFMA launch of the timed edit is on the line whichever registration carries the ops (round 4: the C++ ops bypass
+    # regione_amd.ops, where the timer used to sit): toy trunk = 4 blocks -> 4 attention launches and >= 12 GEMM launches per computed step
+    ra = d["roofline_attention"]
+    assert ra["launches"] > 0 and ra["launches"] % 4 == 0 and rf["launches"] >= 3 * ra["launches"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "steps/s" and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
     assert abs(d["value"] - 28 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
