@@ -38,11 +38,11 @@ def test_full_depth_full_width_full_store_then_region_step_vs_oracle(family):
     assert r["untouched_rows_bit_identical"]
 
 
-@pytest.mark.parametrize("family", ["flux", "qwen"])
+@pytest.mark.parametrize("family", ["flux", "qwen", "step1x_v1p2"])
 def test_full_depth_trunk_28_steps_vs_oracle_denoise(family):
     import parity_full_depth as P
     r = P.narrow_loop(family)
-    assert r["blocks"] == (57 if family == "flux" else 60)
+    assert r["blocks"] == (60 if family == "qwen" else 57)
     assert r["hip_plan"] == r["oracle_plan"] and "R" in r["hip_plan"] and "C" in r["hip_plan"]
     assert r["ids_bit_exact"] and 0 < r["hip_K_e"] < 256
     assert r["oracle_reordered_ids_equal"]

@@ -331,18 +331,22 @@ def narrow_loop(family="flux", grid=16, T=32, device="cuda", hip=True, alt=True)
 def _narrow_loop(family, grid, T, device, hip, alt, t_start):
     h = w = grid
     L = h * w
-    qwen = family == "qwen"
+    qwen, s1x = family == "qwen", family == "step1x_v1p2"
     if qwen:
         cfg = synth.FluxConfig(**dict(synth.QWEN, **dict(NARROW, pooled_dim=768)))
-        Tn, scale, thr_cache = 24, 4.0, 0.03
+        Tn, scale, thr_cache, fam = 24, 4.0, 0.03, "qwen"
+    elif s1x:           # Step1X-Edit v1p2: the FLUX trunk without a guidance embedder, sequential tagged CFG, one K/V cache per tag,
+        cfg = synth.FluxConfig(guidance_embeds=False, **NARROW)        # text lengths 32 / 24 (Step1XEditV1P2/inplace.py:398,416,833,868)
+        Tn, scale, thr_cache, fam = 24, 4.0, 0.02, "step1x_v1p2"
     else:
         cfg = synth.FluxConfig(**NARROW)
-        Tn, scale, thr_cache = None, 1.0, 0.04
+        Tn, scale, thr_cache, fam = None, 1.0, 0.04, "flux"
     w_std = cfg.d ** -0.5
     wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=w_std)
     lat, img0, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=42, dtype=torch.bfloat16)
+    if qwen or s1x:
+        _, _, nprompt, npooled = synth.make_edit_inputs(h, w, Tn, cfg, seed=43, dtype=torch.bfloat16)
     if qwen:
-        _, _, nprompt, _ = synth.make_edit_inputs(h, w, Tn, cfg, seed=43, dtype=torch.bfloat16)
         ocfg = O.FluxCfg(n_double=cfg.n_double, n_single=0, heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim)
         ids_full = torch.arange(2 * L)
     else:
@@ -354,7 +358,7 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
         st = O.RegionState()
         st.set_parameters(28, 6, 2, "16", threshold, thr_cache, True)
 
-        def mk(pe, Tt):
+        def mk(pe, pp, Tt):
             caches = [O.KVCache() for _ in range(cfg.n_layers)]
             rope = O.qwen_rope([(1, h, w), (1, h, w)], Tt) if qwen else None
 
@@ -363,15 +367,15 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
                 tsd = t.expand(x.shape[0]).to(x.dtype)
                 if qwen:
                     return O.transformer_forward(wts, ocfg, st, caches, x, pe, None, tsd / 1000, ids, None, None, rope_full=rope)
-                return O.transformer_forward(wts, ocfg, st, caches, x, pe, pooled, tsd / 1000, ids, torch.zeros(Tt, 3),
-                                             torch.full([1], 2.5, dtype=torch.float32))
+                return O.transformer_forward(wts, ocfg, st, caches, x, pe, pp, tsd / 1000, ids, torch.zeros(Tt, 3),
+                                             None if s1x else torch.full([1], 2.5, dtype=torch.float32))
             return model
         with torch.no_grad():
-            if qwen:
-                out = O.denoise(mk(prompt, T), st, lat, img, ids_full, T, h, w, family="qwen", trace=trace,
-                                neg_model_fn=mk(nprompt, Tn), true_cfg_scale=scale)
+            if qwen or s1x:
+                out = O.denoise(mk(prompt, pooled, T), st, lat, img, ids_full, T, h, w, family=fam, trace=trace,
+                                neg_model_fn=mk(nprompt, npooled, Tn), true_cfg_scale=scale)
             else:
-                out = O.denoise(mk(prompt, T), st, lat, img, ids_full, T, h, w, trace=trace)
+                out = O.denoise(mk(prompt, pooled, T), st, lat, img, ids_full, T, h, w, trace=trace)
         return out, st
 
     # pass 1 (arbitrary condition): the one-step estimate at step warmup-1 -> craft a condition with a compact region
@@ -406,6 +410,9 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
     if qwen:
         from regione_amd.harness import qwen as HQ
         pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, device).load_state_dict(wts))
+    elif s1x:
+        from regione_amd.harness import step1x as HS
+        pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, device).load_state_dict(wts))
     else:
         from regione_amd.harness import flux as H
         pipe = H.FluxKontextPipeline(H.FluxTransformer2DModel(cfg, device).load_state_dict(wts))
@@ -416,6 +423,10 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
     if qwen:
         out = pipe(image=img.to(device), prompt_embeds=prompt.to(device), negative_prompt_embeds=nprompt.to(device),
                    height=h * 16, width=w * 16, latents=lat.to(device), true_cfg_scale=scale, return_dict=False, trace=tr_h)[0]
+    elif s1x:
+        out = pipe(image=img.to(device), prompt_embeds=prompt.to(device), pooled_prompt_embeds=pooled.to(device),
+                   negative_prompt_embeds=nprompt.to(device), negative_pooled_prompt_embeds=npooled.to(device), height=h * 16,
+                   width=w * 16, latents=lat.to(device), true_cfg_scale=scale, return_dict=False, trace=tr_h)[0]
     else:
         out = pipe(image=img.to(device), prompt_embeds=prompt.to(device), pooled_prompt_embeds=pooled.to(device),
                    height=h * 16, width=w * 16, latents=lat.to(device), guidance_scale=2.5, return_dict=False, trace=tr_h)[0]
@@ -436,13 +447,13 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity_full_depth.json"))
-    ap.add_argument("--cases", default="flux_loop,qwen_loop,flux_width,qwen_width")
+    ap.add_argument("--cases", default="flux_loop,qwen_loop,step1x_v1p2_loop,flux_width,qwen_width")
     ap.add_argument("--no-truth", action="store_true", help="skip the fp32 oracle run of the full-width cases")
     ap.add_argument("--no-alt", action="store_true", help="skip the reversed-K oracle run of the full-width cases")
     ns = ap.parse_args()
     report = dict(host_threads=torch.get_num_threads(), cases=[])
     for c in ns.cases.split(","):
-        fam, kind = c.split("_")
+        fam, kind = c.rsplit("_", 1)
         report["cases"].append(narrow_loop(fam) if kind == "loop" else full_width(fam, truth=not ns.no_truth, alt=not ns.no_alt))
     os.makedirs(os.path.dirname(ns.out), exist_ok=True)
     with open(ns.out, "w") as f:
