@@ -23,5 +23,8 @@ cd $R
 python tools/pmc_summary.py $(find /tmp/pm -name "m_results.db" | head -1) > $O/pmc_mfma.json
 python tools/pmc_traffic.py $(find /tmp/prd -name "rd_results.db" | head -1) $(find /tmp/pwr -name "wr_results.db" | head -1) > $O/pmc_traffic.json
 { echo "# rocprofv3 --kernel-trace of: RGN_BENCH_NO_5PCT=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vanilla (5 RegionE edits: 1 warm-up, 1 characterising, 3 timed); bench line of the same process: bench_rocprof_run.json"; python tools/probes/kernel_avg.py $(find /tmp/kt -name "kt_results.db" | head -1); } > $O/kernel_stats.txt
+# the bench line quotes traffic / mfma_busy only from profiles/ files of the SAME kernel sources: put this pass's summaries there first
+cp $O/pmc_mfma.json $R/profiles/r04_pmc_mfma.json; cp $O/pmc_traffic.json $R/profiles/r04_pmc_traffic.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+python bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2>/dev/null
 tail -c 400 $O/bench_default.json; head -12 $O/kernel_stats.txt | cut -c1-160
