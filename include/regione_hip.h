@@ -38,6 +38,11 @@ const char* rgn_last_error(void);
  * reference has no counterpart): bits 0-7 = K pieces of the remainder (1 = none), bit 8 = quarter-tile remainder, bit 10 =
  * 256 x 256 tile geometry. */
 int rgn_gemm_last_plan(void);
+/* The plan the planner WOULD choose for a group of `nprob` (<= 4) problems with M = Ms[i] rows, N output channels, depth K, `distinct_w`
+ * different weight matrices (problems of one stream share W), bf16 (w8 = 0) or fp8 (w8 = 1) weights and a workspace of
+ * `workspace_bytes` (0 = none): same bits as rgn_gemm_last_plan.  Pure host arithmetic on the launch cost model - no launch, no GPU
+ * (CPU tests pin the planner's decisions for the region-step shapes with it); negative RGN_E_* on a bad argument. */
+int rgn_gemm_plan_query(const int* Ms, int nprob, int N, int K, int distinct_w, int w8, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------
  * a1/a2  Adaptive Region Partition.  Replaces token_selector (utils.py:282-354) + morphology
