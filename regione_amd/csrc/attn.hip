@@ -644,6 +644,14 @@ static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, 
     // turn-over on a CU whose LDS one workgroup fills), the merge pass c_m.  Fits the measured region-step shapes within 5 %.
     const float c_t = NW == 8 ? 1.69f : 0.95f, c_p = 10.7f, c_m = 8.0f;
     float best_cost = (float)((left + slots - 1) / slots) * ((float)ntiles * c_t + c_p);
+    // a launch that is ONE partially filled round of 8-wave workgroups runs its KV loop faster than a full chip does (round 4,
+    // tools/probes/attn_plan_sweep.py, no-split launches at Skv 8704 / 2560: 1.10 us per tile with 72 items, 1.19-1.25 with 144, 1.35 with
+    // 192, 1.58 with 240 - fewer CUs share the power budget): the model priced 144 items x 40 tiles at 78 us, split them (70 us) and lost
+    // to the plain launch (56 us); 192 items x 136 tiles: stream-K 204 us against 194.5 us plain
+    if (NW == 8 && full == 0 && left > 0) {
+        const float x = fmaxf(0.0f, (float)(left - 72) / 184.0f);
+        best_cost = (float)ntiles * (1.10f + 0.59f * x * x) + c_p;
+    }
     bool stream_k = false;
     if (left > 0 && ws != nullptr) {
         for (int S = 2; S <= 8; ++S) {
