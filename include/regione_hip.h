@@ -302,6 +302,12 @@ int rgn_attention_bounded(const void* Q, int ldq, const void* k_slab, const void
  * combine kernel.  NULL disables the split (results are identical up to fp32 summation order).  The returned size (128 MiB)
  * is a shape-independent upper bound; a smaller buffer limits the piece count.  One workspace per stream. */
 size_t rgn_attention_workspace_bytes(int Sq, int H);
+/* Introspection of the round-aware schedule (tests, traces; no reference counterpart): the plan of the last rgn_attention* call on this
+ * thread / the plan the scheduler WOULD choose for (Sq, Skv, H) with a workspace of `workspace_bytes` (0 = none) - pure host arithmetic,
+ * no launch, no GPU.  Bits 0-3 = equal KV pieces of the remainder items (1 = not split), bit 4 = stream-K remainder, bit 5 = 8-wave
+ * workgroups (256 query rows; clear = 4 waves x 128 rows for tiny query sets). */
+int rgn_attention_last_plan(void);
+int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes);
 
 /* Device properties the host side needs for roofline reporting (no torch types). */
 int rgn_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes);

@@ -45,6 +45,8 @@ _prob_p = C.POINTER(GemmProblem)
 SIGNATURES = {
     "rgn_version": [],
     "rgn_gemm_last_plan": [],
+    "rgn_attention_last_plan": [],
+    "rgn_attention_plan_query": [_c_int, _c_int, _c_int, C.c_size_t],
     "rgn_gemm_plan_query": [C.POINTER(C.c_int), _c_int, _c_int, _c_int, _c_int, _c_int, C.c_size_t],
     "rgn_last_error": [],
     "rgn_device_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)],

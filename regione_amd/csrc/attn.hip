@@ -633,8 +633,11 @@ static int launch_attention(const AttnArgs& g, hipStream_t st) {
 // the REMAINDER (which would otherwise occupy a full round at partial occupancy - 816 items on 256
 // CUs = 3.19 rounds -> 4) is cut along KV into `nsplit` ranges so that it spreads over all CUs, and
 // merged by a tiny combine kernel.
+static thread_local int g_last_attn_plan = 0;     // what attention_schedule chose last on this thread: bits 0-3 = equal KV pieces of the
+                                                   // remainder (1 = none), bit 4 = stream-K remainder, bit 5 = 8-wave workgroups
+
 template <int NW, int NSTAGE>
-static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, hipStream_t st) {
+static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, hipStream_t st, bool dry = false) {
     constexpr int QB = 32 * NW;
     const int nitems = g.H * ((g.Sq + QB - 1) / QB);
     const int ntiles = (g.Skv + KV_T - 1) / KV_T;
@@ -672,6 +675,8 @@ static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, 
             if (cost < best_cost - 1e-3f || atoi(sk_env ? sk_env : "1") == 2) { best_cost = cost; stream_k = true; }   // 2: forced (tests)
         }
     }
+    g_last_attn_plan = (stream_k ? 1 : best) | (stream_k ? 0x10 : 0) | (NW == 8 ? 0x20 : 0);
+    if (dry) return 0;                                  // rgn_attention_plan_query: the plan only
     g.ws = (float*)ws;
     g.nsplit = 1;
     int rc = 0;
@@ -744,6 +749,21 @@ int rgn_attention_bounded(const void* Q, int ldq, const void* k_slab, const void
     if (v && v[1] == 'n') { workspace = nullptr; workspace_bytes = 0; }        // "8n" / "4n": no KV split
     if (variant == 8) return attention_schedule<8, 3>(g, 256, workspace, workspace_bytes, st);
     return attention_schedule<4, 2>(g, 512, workspace, workspace_bytes, st);
+}
+
+int rgn_attention_last_plan(void) { return g_last_attn_plan; }
+
+int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes) {
+    if (Sq <= 0 || Skv <= 0 || H <= 0) return fail(RGN_E_BADARG, "attention_plan_query: bad argument");
+    AttnArgs g{};
+    g.Sq = Sq; g.Skv = Skv; g.H = H; g.skv_pad = (Skv + 63) / 64 * 64;
+    int variant = (H * ((Sq + 255) / 256) >= 96) ? 8 : 4;
+    const char* v = getenv("RGN_ATTN_VARIANT");
+    if (v && (v[0] == '4' || v[0] == '8')) variant = v[0] - '0';
+    void* ws = (workspace_bytes > 0 && !(v && v[1] == 'n')) ? (void*)(uintptr_t)64 : nullptr;      // never dereferenced in a dry run
+    if (variant == 8) (void)attention_schedule<8, 3>(g, 256, ws, ws ? workspace_bytes : 0, nullptr, true);
+    else (void)attention_schedule<4, 2>(g, 512, ws, ws ? workspace_bytes : 0, nullptr, true);
+    return g_last_attn_plan;
 }
 
 }  // extern "C"

@@ -69,3 +69,41 @@ def test_bad_arguments_are_refused():
     assert _lib.lib().rgn_gemm_plan_query(arr, 1, 3072, 100, 1, 0, WS) < 0          # K not a multiple of 64
     assert _lib.lib().rgn_gemm_plan_query(arr, 5, 3072, 128, 1, 0, WS) < 0          # more than four problems
     assert _lib.lib().rgn_gemm_plan_query(None, 1, 3072, 128, 1, 0, WS) < 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# attention_schedule (attn.hip) through rgn_attention_plan_query: the remainder schedule per (Sq, Skv), as measured by
+# tools/probes/attn_plan_sweep.py (profiles/r04_attn_plan_sweep_after_fix.txt)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def aplan(Sq, Skv, H=24, ws=128 << 20):
+    p = _lib.lib().rgn_attention_plan_query(Sq, Skv, H, ws)
+    assert p >= 0, p
+    return dict(pieces=p & 15, stream_k=bool(p & 16), waves8=bool(p & 32))
+
+
+@pytest.fixture(autouse=True)
+def no_attention_switches(monkeypatch):
+    for k in ("RGN_ATTN_VARIANT", "RGN_ATTN_STREAMK", "RGN_ATTN_ASM"):
+        monkeypatch.delenv(k, raising=False)
+
+
+@pytest.mark.parametrize("Sq,Skv,want", [
+    (1536, 8704, dict(pieces=1, stream_k=True, waves8=True)),        # FLUX region step at K_e 25 %: 144 items -> stream-K (171 vs 176 / 182 us)
+    (1137, 8704, dict(pieces=2, stream_k=False, waves8=True)),       # K_e 15 %: 120 items x 2 equal pieces = one round (126 vs 149 us stream-K)
+    (2048, 8704, dict(pieces=1, stream_k=False, waves8=True)),       # 192 items: the plain launch (194.5 vs 204 us stream-K) - round-4 fix
+    (1536, 2560, dict(pieces=1, stream_k=False, waves8=True)),       # 144 items x 40 KV tiles: plain (56 us; the round-3 model split it: 70 us)
+    (8704, 8704, dict(pieces=5, stream_k=False, waves8=True)),       # full step: 816 items = 3 rounds + 48 -> the remainder in 5 equal pieces
+])
+def test_attention_remainder_schedules(Sq, Skv, want):
+    assert aplan(Sq, Skv) == want
+
+
+def test_attention_plan_switches_and_small_query_sets(monkeypatch):
+    assert not aplan(576, 8704)["waves8"]                            # 72 items of 256 rows < 96: 4-wave workgroups of 128 rows
+    assert aplan(1536, 8704, ws=0) == dict(pieces=1, stream_k=False, waves8=True)     # no workspace: no partials
+    monkeypatch.setenv("RGN_ATTN_STREAMK", "0")
+    p = aplan(1536, 8704)
+    assert not p["stream_k"]
+    monkeypatch.setenv("RGN_ATTN_STREAMK", "2")
+    assert aplan(1137, 8704)["stream_k"]
+    assert _lib.lib().rgn_attention_plan_query(0, 8704, 24, 0) < 0
