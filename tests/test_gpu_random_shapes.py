@@ -16,10 +16,13 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
-def _check(out, ref, what, atol=1e-2, ulp=2 ** -8):
-    """|out - ref| <= ulp * |ref| + atol elementwise (ref in fp64: one bf16 rounding + accumulation noise of O(sqrt(K)) products)"""
+def _check(out, ref, what, atol=1e-2, ulp=2 ** -8, extra=None):
+    """|out - ref| <= ulp * |ref| + atol (+ extra) elementwise (ref in fp64: one bf16 rounding + accumulation noise of O(sqrt(K))
+    products; `extra`: an elementwise allowance the caller derives, e.g. the gate-amplified rounding of the linear result)"""
     err = (out.double() - ref).abs()
     tol = ulp * ref.abs() + atol
+    if extra is not None:
+        tol = tol + extra
     bad = err > tol
     assert not bool(bad.any()), f"{what}: {int(bad.sum())} elements off, worst {float((err / tol).max()):.2f} x tolerance"
 
@@ -118,7 +121,13 @@ def test_gemm_random_groups_match_separate_launches(seed, split, monkeypatch):
             if split == "0":
                 assert torch.equal(p.out, o_s), tag
             else:
-                _check(p.out, o_s.double(), tag, atol=2e-2, ulp=2 ** -7)
+                # the two launches may sum K in a different order (another piece count / geometry): bf16(lin) can differ by ONE
+                # rounding, and the gated-residual epilogue multiplies that by the gate before adding the residual
+                extra = None
+                if epi == 2:
+                    lin = (A.double() @ W.double().T + b.double()).abs()
+                    extra = gate.double().abs()[None, :] * lin * 2.0 ** -8
+                _check(p.out, o_s.double(), tag, atol=2e-2, ulp=2 ** -7, extra=extra)
 
 
 @pytest.mark.parametrize("seed", range(6))
