@@ -122,11 +122,12 @@ def test_gemm_random_groups_match_separate_launches(seed, split, monkeypatch):
                 assert torch.equal(p.out, o_s), tag
             else:
                 # the two launches may sum K in a different order (another piece count / geometry): bf16(lin) can differ by ONE
-                # rounding, and the gated-residual epilogue multiplies that by the gate before adding the residual
+                # rounding; the gated-residual epilogue multiplies that by the gate and rounds the product to bf16 again before adding
+                # the residual - two roundings of size 2^-8 |gate * lin|
                 extra = None
                 if epi == 2:
                     lin = (A.double() @ W.double().T + b.double()).abs()
-                    extra = gate.double().abs()[None, :] * lin * 2.0 ** -8
+                    extra = gate.double().abs()[None, :] * lin * 2.0 ** -7
                 _check(p.out, o_s.double(), tag, atol=2e-2, ulp=2 ** -7, extra=extra)
 
 
