@@ -7,7 +7,7 @@
 namespace rgn {
 
 // ------------------------------------------------------------------------------------------------
-// y = bf16(bf16(bf16(LN(x)) * bf16(1 + scale)) + shift), one wave per row, two-pass stats in registers
+// y = bf16(bf16(bf16(LN(x)) * bf16(1 + scale)) + shift), one 256-thread block per row, two-pass stats
 // ------------------------------------------------------------------------------------------------
 // Row segments with their own modulation vectors: rows [end[i-1], end[i]) use (shift[i], scale[i]) - the text / image
 // streams of a double block, times the CFG branches of a batched forward (per-branch AdaLN vectors).
@@ -18,15 +18,11 @@ struct LnSegs {
     const uint16_t* scale[LN_MAXSEG];
 };
 
-// One WAVE per row, four rows per workgroup (round 4): every lane requests all of its 16-byte vectors of the row before the first
-// reduction (6 in flight at d = 3072), statistics are wave reductions - no LDS, no barriers.  The one-workgroup-per-row form it replaces
-// spent two block barriers per 6 KB row and ran at 3.3 TB/s.
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const uint16_t* __restrict__ x, int ldx,
-                                                          uint16_t* __restrict__ out, int ldo, int M, int d, float eps,
+                                                          uint16_t* __restrict__ out, int ldo, int d, float eps,
                                                           const LnSegs segs) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint16_t* xr = x + (size_t)row * ldx;
     int si = 0;
 #pragma unroll
@@ -34,46 +30,48 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const uint16_t* __rest
     const uint16_t* sh = segs.shift[si];
     const uint16_t* sc = segs.scale[si];
     const int nvec = d >> 3;
-    constexpr int MAXV = 16;                      // d <= 8192
-    uint4 raw[MAXV];
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int vi = lane + i * 64;
-        if (vi < nvec) raw[i] = *(const uint4*)(xr + vi * 8);
-    }
+    constexpr int MAXV = 4;                       // d <= 8192
+    float v[MAXV][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        if (lane + i * 64 < nvec) {
-            const uint16_t* t = (const uint16_t*)&raw[i];
+        const int vi = tid + i * 256;
+        if (vi < nvec) {
+            uint16_t t[8];
+            *(uint4*)t = *(const uint4*)(xr + vi * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += bf2f(t[e]);
+            for (int e = 0; e < 8; ++e) { v[i][e] = bf2f(t[e]); s += v[i][e]; }
         }
     }
-    const float mean = wave_sum(s) / (float)d;
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        if (lane + i * 64 < nvec) {
-            const uint16_t* t = (const uint16_t*)&raw[i];
+        const int vi = tid + i * 256;
+        if (vi < nvec) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float c = bf2f(t[e]) - mean; q += c * c; }
+            for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; q += c * c; }
         }
     }
-    const float var = wave_sum(q) / (float)d;
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)d;
     const float rstd = 1.0f / sqrtf(var + eps);
     uint16_t* orow = out + (size_t)row * ldo;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
-        const int vi = lane + i * 64;
+        const int vi = tid + i * 256;
         if (vi < nvec) {
-            const uint16_t* t = (const uint16_t*)&raw[i];
             uint16_t a[8], b[8], o[8];
             *(uint4*)a = *(const uint4*)(sc + vi * 8);
             *(uint4*)b = *(const uint4*)(sh + vi * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float y0 = rbf((bf2f(t[e]) - mean) * rstd);       // LayerNorm output (bf16)
+                const float y0 = rbf((v[i][e] - mean) * rstd);          // LayerNorm output (bf16)
                 const float s1 = rbf(1.0f + bf2f(a[e]));                // (1 + scale) (bf16)
                 const float y1 = rbf(y0 * s1);
                 o[e] = f2bf(y1 + bf2f(b[e]));
@@ -212,8 +210,8 @@ int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, fl
         segs.shift[i] = (const uint16_t*)(i == 0 && split_row > 0 ? shift0 : shift1);
         segs.scale[i] = (const uint16_t*)(i == 0 && split_row > 0 ? scale0 : scale1);
     }
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
-                       (uint16_t*)out, ldo, M, d, eps, segs);
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+                       (uint16_t*)out, ldo, d, eps, segs);
     return check_launch("ln_modulate_kernel");
 }
 
@@ -234,8 +232,8 @@ int rgn_ln_modulate_segs(const void* x, int ldx, void* out, int ldo, int M, int 
         prev = seg_end_host[j];
     }
     if (seg_end_host[nseg - 1] != M) return fail(RGN_E_BADARG, "ln_modulate_segs: the last segment must end at M");
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
-                       (uint16_t*)out, ldo, M, d, eps, segs);
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
+                       (uint16_t*)out, ldo, d, eps, segs);
     return check_launch("ln_modulate_kernel");
 }
 
