@@ -19,6 +19,7 @@
 // | kv_partial_update_[pair_|group_] | _partially_linear x2 + norm_k + RoPE into the caches, inplace.py:734-794, fused_kernels.py:81-101 |
 // | region_attention         | flash_attn_func / SDPA of the edited-token queries vs the full cache, inplace.py:796-806 |
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -39,6 +40,9 @@ using OptTensor = std::optional<Tensor>;
 void check_rc(int rc, const char* what) {
     TORCH_CHECK(rc == 0, what, " failed (rc ", rc, "): ", rgn_last_error());
 }
+
+// every op runs on the device of its first tensor argument (a process that drives several GPUs may call with another device current)
+#define RGN_DEVICE_GUARD(t) const c10::hip::HIPGuard rgn_device_guard((t).device())
 
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
 
@@ -97,6 +101,7 @@ Tensor attn_ws(const Tensor& like) { return workspace(1, like, rgn_attention_wor
 std::tuple<Tensor, Tensor, Tensor> arp_partition(const Tensor& sample, const OptTensor& model_output, const Tensor& cond,
                                                  double dt_final, double threshold, int64_t h_tok, int64_t w_tok,
                                                  bool erosion_dilation) {
+    RGN_DEVICE_GUARD(sample);
     Tensor s = rows(sample), c = rows(cond);
     OptTensor mo;
     if (model_output.has_value() && model_output->defined()) mo = rows(*model_output);
@@ -115,6 +120,7 @@ std::tuple<Tensor, Tensor, Tensor> arp_partition(const Tensor& sample, const Opt
 }
 
 Tensor gather_rows(const Tensor& x, const Tensor& ids) {
+    RGN_DEVICE_GUARD(x);
     Tensor src = rows(x), idv = ids.reshape({-1}).contiguous();
     TORCH_CHECK(idv.scalar_type() == at::kLong, "gather_rows: ids must be int64");
     Tensor out = at::empty({idv.numel(), src.size(1)}, src.options());
@@ -124,6 +130,7 @@ Tensor gather_rows(const Tensor& x, const Tensor& ids) {
 }
 
 void scatter_rows_(const Tensor& src, const Tensor& ids, Tensor dst) {
+    RGN_DEVICE_GUARD(src);
     Tensor s = rows(src), d = rows(dst), idv = ids.reshape({-1}).contiguous();
     TORCH_CHECK(idv.scalar_type() == at::kLong && s.size(1) == d.size(1) && s.scalar_type() == d.scalar_type(), "scatter_rows_: arguments");
     check_rc(rgn_scatter_rows(ptr(s), (const int64_t*)ptr(idv), d.data_ptr(), (int)idv.numel(), (int)(s.size(1) * s.element_size()),
@@ -131,6 +138,7 @@ void scatter_rows_(const Tensor& src, const Tensor& ids, Tensor dst) {
 }
 
 Tensor split_euler_step(const Tensor& sample, const Tensor& v, double dt_, const OptTensor& mask, double dt_direct) {
+    RGN_DEVICE_GUARD(sample);
     Tensor s = rows(sample), vv = rows(v);
     TORCH_CHECK(s.sizes() == vv.sizes(), "split_euler_step: shapes");
     Tensor out = at::empty_like(vv);
@@ -140,6 +148,7 @@ Tensor split_euler_step(const Tensor& sample, const Tensor& v, double dt_, const
 }
 
 Tensor avd_apply(const Tensor& cache, double ratio, const OptTensor& ids, bool round_ratio) {
+    RGN_DEVICE_GUARD(cache);
     Tensor c = rows(cache);
     OptTensor idv;
     if (ids.has_value() && ids->defined()) idv = ids->reshape({-1}).contiguous();
@@ -151,6 +160,7 @@ Tensor avd_apply(const Tensor& cache, double ratio, const OptTensor& ids, bool r
 }
 
 Tensor cfg_combine(const Tensor& pos, const Tensor& neg, double scale, int64_t mode, double power) {
+    RGN_DEVICE_GUARD(pos);
     Tensor p = rows(pos), n = rows(neg);
     TORCH_CHECK(p.sizes() == n.sizes() && p.scalar_type() == n.scalar_type(), "cfg_combine: shapes");
     Tensor out = at::empty_like(p);
@@ -197,6 +207,7 @@ void kv_partial_update_(const Tensor& x, const Tensor& w_kvq, const OptTensor& b
                         const Tensor& norm_k, const Tensor& cos_q, const Tensor& sin_q, const Tensor& cos_k, const Tensor& sin_k,
                         const OptTensor& kv_rows, Tensor k_cache, Tensor vt_cache, int64_t heads, int64_t row_base, double eps,
                         bool fp16_roundtrip, int64_t gelu_from_col, const OptTensor& w_scale) {
+    RGN_DEVICE_GUARD(x);
     check_act(x, w_kvq, q_out, w_scale);
     rgn_qkv_epilogue e = epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip);
     const int gelu = (int)(gelu_from_col < 0 ? 3 * heads * 128 : gelu_from_col);
@@ -220,6 +231,7 @@ void kv_partial_update_pair_(const Tensor& x_img, const Tensor& w_img, const Opt
                              const Tensor& cos_k, const Tensor& sin_k, const OptTensor& kv_rows, Tensor k_cache, Tensor vt_cache,
                              int64_t heads, int64_t txt_len, double eps, bool fp16_roundtrip, const OptTensor& w_scale_img,
                              const OptTensor& w_scale_txt) {
+    RGN_DEVICE_GUARD(x_img);
     check_act(x_img, w_img, out_img, w_scale_img);
     check_act(x_txt, w_txt, out_txt, w_scale_txt);
     TORCH_CHECK(w_img.sizes() == w_txt.sizes() && w_img.is_contiguous() && w_txt.is_contiguous() && is_fp8(w_img) == is_fp8(w_txt),
@@ -250,6 +262,8 @@ void kv_partial_update_group_(at::TensorList x, at::TensorList w_kvq, const c10:
                               at::TensorList vt_cache, int64_t heads, at::IntArrayRef row_base, double eps, at::IntArrayRef fp16_roundtrip,
                               int64_t gelu_from_col) {
     const size_t n = x.size();
+    TORCH_CHECK(n >= 1, "kv_partial_update_group_: no problems");
+    RGN_DEVICE_GUARD(x[0]);
     TORCH_CHECK(n >= 1 && n <= 4 && w_kvq.size() == n && b_kvq.size() == n && q_out.size() == n && norm_q.size() == n && norm_k.size() == n &&
                     cos_q.size() == n && sin_q.size() == n && cos_k.size() == n && sin_k.size() == n && kv_rows.size() == n &&
                     k_cache.size() == n && vt_cache.size() == n && row_base.size() == n && (fp16_roundtrip.empty() || fp16_roundtrip.size() == n) &&
@@ -279,6 +293,7 @@ void kv_partial_update_group_(at::TensorList x, at::TensorList w_kvq, const c10:
 
 void region_attention(const Tensor& q, const Tensor& k_cache, const Tensor& vt_cache, Tensor out, int64_t skv, int64_t heads, double scale,
                       double score_bound) {
+    RGN_DEVICE_GUARD(q);
     TORCH_CHECK(q.dim() == 2 && out.dim() == 2 && q.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16 &&
                     q.stride(1) == 1 && out.stride(1) == 1 && q.size(1) == heads * 128 && out.sizes() == q.sizes(), "region_attention: q / out [Sq, H*128] bf16");
     TORCH_CHECK(k_cache.dim() == 2 && k_cache.size(1) == heads * 128 && k_cache.is_contiguous() && vt_cache.is_contiguous() &&
