@@ -19,7 +19,7 @@
 // | kv_partial_update_[pair_|group_] | _partially_linear x2 + norm_k + RoPE into the caches, inplace.py:734-794, fused_kernels.py:81-101 |
 // | region_attention         | flash_attn_func / SDPA of the edited-token queries vs the full cache, inplace.py:796-806 |
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -42,7 +42,8 @@ void check_rc(int rc, const char* what) {
 }
 
 // every op runs on the device of its first tensor argument (a process that drives several GPUs may call with another device current)
-#define RGN_DEVICE_GUARD(t) const c10::hip::HIPGuard rgn_device_guard((t).device())
+// (c10::DeviceGuard, not c10::hip::HIPGuard: PyTorch-ROCm tensors carry DeviceType "cuda" and the plain HIP guard refuses them)
+#define RGN_DEVICE_GUARD(t) const c10::DeviceGuard rgn_device_guard((t).device())
 
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
 
