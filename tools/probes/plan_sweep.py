@@ -27,9 +27,17 @@ SCHEDULES += [(f"256 S={s}", {"RGN_GEMM_VARIANT": "3", "RGN_GEMM_NSPLIT": str(s)
 SCHEDULES += [("256 quarter", {"RGN_GEMM_VARIANT": "3", "RGN_GEMM_QUARTER": "2"})]
 
 
-def shapes(dense=False):
+def shapes(dense=False, full=False):
     out = []
     T = 512
+    if full:              # the FULL-step launches (88 % of the headline edit): FLUX 1024^2, Qwen batched branches, Step1X 512^2 batched
+        for fam, ms1, ms2 in (("FLUX F", [8192, T], [8704]), ("S1X512 F", [2048, 2048, T, T], [2560, 2560])):
+            out += [(f"{fam} qkv", ms1, 9216, 3072, "bias"), (f"{fam} out", ms1, 3072, 3072, "gate"), (f"{fam} ff1", ms1, 12288, 3072, "gelu"),
+                    (f"{fam} ff2", ms1, 3072, 12288, "gate"), (f"{fam} kvq+mlp", ms2, 21504, 3072, "gelu"), (f"{fam} proj_out", ms2, 3072, 15360, "gate")]
+        ms = [8192, 8192, 512, 384]
+        out += [("Qwen F qkv", ms, 9216, 3072, "bias"), ("Qwen F out", ms, 3072, 3072, "gate"), ("Qwen F ff1", ms, 12288, 3072, "gelu"),
+                ("Qwen F ff2", ms, 3072, 12288, "gate")]
+        return out
     if dense:             # the long-K / small-N projections across K_e: where the 128 geometry, split-K and the plain launch trade places
         for ke in range(64, 2177, 96):
             out += [(f"FLUX Ke{ke} ff2", [ke, T], 3072, 12288, "gate"), (f"FLUX Ke{ke} proj_out", [T + ke], 3072, 15360, "gate"),
@@ -55,9 +63,10 @@ def main():
     ap.add_argument("--only", default=None)
     ap.add_argument("--json", default=None)
     ap.add_argument("--dense", action="store_true", help="K_e sweep of the long-K projections instead of the family table")
+    ap.add_argument("--full", action="store_true", help="the full-step launches instead")
     ns = ap.parse_args()
     rows = []
-    for name, Ms, N, K, epi in shapes(ns.dense):
+    for name, Ms, N, K, epi in shapes(ns.dense, ns.full):
         if ns.only and ns.only not in name:
             continue
         # problems 0/1 (image rows of the two branches) share one weight matrix, 2/3 (text rows) the other - like the engine
