@@ -341,17 +341,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// Stream-K run boundaries (round 4): the flattened (item, KV tile) steps are dealt out in G runs of equal COST, not equal length.  A run
-// that crosses an item boundary starts a second segment - Q load, ring fill, partial dump: ~SK_PAD tile times (c_p / c_t of
-// attention_schedule) - so every item start is padded with SK_PAD virtual steps and the runs are equal in the padded space; crossing
-// runs get that many fewer tiles.  With fewer items than runs a run still spans at most one item boundary.
-constexpr int SK_PAD = 6;
-__host__ __device__ __forceinline__ long long sk_bound(int w, int G, int nitems, int nt) {
-    const long long P = nt + SK_PAD, v = (long long)w * ((long long)nitems * P) / G;
-    const long long u = v / P, r = v - u * P;
-    return u * nt + (r > SK_PAD ? r - SK_PAD : 0);
-}
-
 // SPLIT: 0 = one workgroup per item (256 query rows of one head against every KV tile), result written in place;
 //        1 = every item cut into g.nsplit equal KV ranges (partials to g.ws, attention_combine_kernel merges);
 //        2 = stream-K: the (item, KV tile) steps of the launch, flattened item-major, are dealt out in equal contiguous
@@ -374,8 +363,9 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
     }
     int sk_lo = 0, sk_hi = 0, seg = 0;
     if (SPLIT == 2) {
-        sk_lo = (int)sk_bound(unit, (int)gridDim.x, g.nitems_launch, ntiles_all);
-        sk_hi = (int)sk_bound(unit + 1, (int)gridDim.x, g.nitems_launch, ntiles_all);
+        const long long total = (long long)g.nitems_launch * ntiles_all;
+        sk_lo = (int)((long long)unit * total / (int)gridDim.x);
+        sk_hi = (int)((long long)(unit + 1) * total / (int)gridDim.x);
         if (sk_lo >= sk_hi) return;
     }
     const uint32_t HD2 = (uint32_t)g.H * 256u;                 // bytes of one K row (H * 128 bf16)
@@ -568,7 +558,7 @@ __global__ __launch_bounds__(256) void attention_combine_sk_kernel(const AttnArg
     const int nt = g.Skv / KV_T;
     const long long total = (long long)g.nitems_launch * nt;
     const long long lo = (long long)u * nt, hi = lo + nt;
-    auto bound = [&](int w) { return sk_bound(w, G, g.nitems_launch, nt); };
+    auto bound = [&](int w) { return (long long)w * total / G; };
     int w0 = (int)(lo * G / total);
     while (w0 + 1 < G && bound(w0 + 1) <= lo) ++w0;
     while (w0 > 0 && bound(w0) > lo) --w0;
@@ -681,8 +671,7 @@ static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, 
         const long long steps = (long long)left * ntiles;
         if (NW == 8 && (sk_env ? atoi(sk_env) : 1) && attention_use_asm(g) && left < slots && steps >= 8LL * slots &&
             (size_t)slots * 2 * QB * 130 * sizeof(float) <= ws_bytes) {
-            // runs of equal cost (sk_bound): every item start is worth SK_PAD tiles, every run pays one prologue of its own
-            const float cost = (float)((steps + (long long)SK_PAD * left + slots - 1) / slots) * c_t + c_p + c_m;
+            const float cost = (float)((steps + slots - 1) / slots) * c_t + 2.0f * c_p + c_m;
             if (cost < best_cost - 1e-3f || atoi(sk_env ? sk_env : "1") == 2) { best_cost = cost; stream_k = true; }   // 2: forced (tests)
         }
     }
