@@ -129,7 +129,8 @@ int rgn_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bi
                   void* stream);
 /* `workspace` (optional, fp32 scratch, rgn_gemm_workspace_bytes()) enables the round-aware schedule:
  * output tiles that do not fill a whole round of the chip's workgroup slots are cut along K, spread
- * over all CUs and finished by a reduce pass.  NULL = plain single launch.
+ * over all CUs and finished by a reduce pass (8 workgroups per tile, epilogue in registers; bit-identical to a reduce by the
+ * tile's own workgroup).  NULL = plain single launch.
  * Sizing: rgn_gemm_workspace_bytes() is a shape-independent upper bound (256 MiB = 255 remainder tiles x 4 pieces x 256 KiB of
  * fp32 fragments, plus room for the fp8 weight widening of rgn_gemm_w8*); any smaller buffer is valid too - the planner only
  * considers piece counts whose partials fit in `workspace_bytes` (and skips the split / the widening when nothing fits).
@@ -210,9 +211,10 @@ int rgn_gemm_group(const rgn_gemm_problem* probs, int nprob, int N, int K, int e
  * the LDS read), the scale multiplies the fp32 accumulator.  Replaces nothing in the reference (which ships bf16 weights):
  * storage format of the [EXT] Linear weights only; quantisation (per-channel absmax / 448) is done by the caller
  * (regione_amd.harness.flux.FluxTransformer2DModel.quantize_fp8_).
- * With a workspace and >= 2048 rows in total the call first widens W8 to bf16 (exact) into the TAIL of the workspace
- * (N x K x 2 bytes per problem, >= 64 MiB left for the split remainders) and runs the bf16 K loop on it - same result bit
- * for bit, weights stay fp8 in HBM (env RGN_W8_WIDEN_MIN_M, 0 = never). */
+ * Default since round 3: the fp8 tiles are converted in registers inside the hand-scheduled K loop.  A/B switch RGN_W8_WIDEN_MIN_M=<rows>
+ * (default 0 = never): with a workspace and at least that many rows in total the call first widens W8 to bf16 (exact) into the TAIL
+ * of the workspace (N x K x 2 bytes per distinct weight matrix, >= 64 MiB left for the split remainders) and runs the bf16 K loop on
+ * it - same result bit for bit, weights stay fp8 in HBM. */
 int rgn_gemm_w8(const void* A, int lda, const void* W8, int ldw, const float* wscale, const void* bias, void* C, int ldc,
                 int M, int N, int K, int epilogue, int gelu_from_col, const void* gate, const void* resid,
                 const int64_t* out_rows, void* workspace, size_t workspace_bytes, void* stream);
