@@ -107,3 +107,9 @@ def test_attention_plan_switches_and_small_query_sets(monkeypatch):
     monkeypatch.setenv("RGN_ATTN_STREAMK", "2")
     assert aplan(1137, 8704)["stream_k"]
     assert _lib.lib().rgn_attention_plan_query(0, 8704, 24, 0) < 0
+
+
+def test_full_step_ff_up_pair_splits_its_96_tile_remainder():
+    # 1632 tiles = 6 whole rounds + 96: two K pieces for the remainder (522 -> 501 us measured; the 2.5 % acceptance threshold of round 4)
+    assert plan((8192, 512), 12288, 3072) == dict(big=True, pieces=2, quarter=False)
+    assert plan((8192, 512), 9216, 3072) == dict(big=True, pieces=1, quarter=False)          # Q/K/V pair: 4 rounds + 200, plain (364 vs 396 us)
