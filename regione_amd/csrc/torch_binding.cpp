@@ -142,6 +142,9 @@ Tensor split_euler_step(const Tensor& sample, const Tensor& v, double dt_, const
     RGN_DEVICE_GUARD(sample);
     Tensor s = rows(sample), vv = rows(v);
     TORCH_CHECK(s.sizes() == vv.sizes(), "split_euler_step: shapes");
+    TORCH_CHECK(!(mask.has_value() && mask->defined()) ||
+                    (mask->scalar_type() == at::kByte && mask->is_contiguous() && mask->numel() == s.size(0)),
+                "split_euler_step: mask must be uint8 [L] (the third result of arp_partition)");
     Tensor out = at::empty_like(vv);
     check_rc(rgn_euler_step(ptr(s), dt(s), ptr(vv), dt(vv), out.data_ptr(), (const uint8_t*)ptr(mask), (float)dt_, (float)dt_direct,
                             (int)s.size(0), (int)s.size(1), stream_of(s)), "rgn_euler_step");
@@ -152,7 +155,10 @@ Tensor avd_apply(const Tensor& cache, double ratio, const OptTensor& ids, bool r
     RGN_DEVICE_GUARD(cache);
     Tensor c = rows(cache);
     OptTensor idv;
-    if (ids.has_value() && ids->defined()) idv = ids->reshape({-1}).contiguous();
+    if (ids.has_value() && ids->defined()) {
+        TORCH_CHECK(ids->scalar_type() == at::kLong, "avd_apply: ids must be int64");   // read as 8-byte indices
+        idv = ids->reshape({-1}).contiguous();
+    }
     const int64_t K = idv ? idv->numel() : c.size(0);
     Tensor out = at::empty({K, c.size(1)}, c.options());
     check_rc(rgn_avd_apply(ptr(c), dt(c), (const int64_t*)ptr(idv), (float)ratio, (int)round_ratio, out.data_ptr(), (int)K,
@@ -177,6 +183,9 @@ rgn_qkv_epilogue epi(const Tensor& norm_q, const Tensor& norm_k, const Tensor& c
     const int64_t d = heads * 128, skv_pad = k_cache.size(0);
     TORCH_CHECK(k_cache.dim() == 2 && k_cache.size(1) == d && vt_cache.dim() == 2 && vt_cache.size(0) == d && vt_cache.size(1) == skv_pad &&
                     k_cache.is_contiguous() && vt_cache.is_contiguous(), "K slab [skv_pad, H*128] / V^T slab [H*128, skv_pad], contiguous");
+    for (const Tensor* t : {&norm_q, &norm_k})
+        TORCH_CHECK(t->scalar_type() == at::kBFloat16 && t->numel() == 128 && t->is_contiguous(), "per-head RMSNorm weights: bf16 [128]");
+    TORCH_CHECK(cos_q.sizes() == sin_q.sizes() && cos_k.sizes() == sin_k.sizes(), "rotary tables: cos / sin of one table differ in shape");
     for (const Tensor* t : {&cos_q, &sin_q, &cos_k, &sin_k})
         TORCH_CHECK(t->scalar_type() == at::kFloat && t->dim() == 2 && t->size(1) == 128 && t->is_contiguous(), "rotary tables: fp32 [rows, 128]");
     // the kernel reads 8-byte indices: an int32 tensor would be read past its end and scatter K / V to garbage cache rows
@@ -299,6 +308,7 @@ void region_attention(const Tensor& q, const Tensor& k_cache, const Tensor& vt_c
                     q.stride(1) == 1 && out.stride(1) == 1 && q.size(1) == heads * 128 && out.sizes() == q.sizes(), "region_attention: q / out [Sq, H*128] bf16");
     TORCH_CHECK(k_cache.dim() == 2 && k_cache.size(1) == heads * 128 && k_cache.is_contiguous() && vt_cache.is_contiguous() &&
                     vt_cache.size(0) == heads * 128 && vt_cache.size(1) == k_cache.size(0), "region_attention: cache slabs");
+    TORCH_CHECK(skv >= 1 && skv <= k_cache.size(0), "region_attention: skv = ", skv, " outside the cache slab's ", k_cache.size(0), " rows");
     Tensor ws = attn_ws(q);
     check_rc(rgn_attention_bounded(ptr(q), (int)q.stride(0), ptr(k_cache), ptr(vt_cache), (int)k_cache.size(0), out.data_ptr(), (int)out.stride(0),
                                    (int)q.size(0), (int)skv, (int)heads, (float)(scale > 0 ? scale : 1.0 / std::sqrt(128.0)), (float)score_bound,

@@ -115,6 +115,8 @@ def scatter_rows_(src: torch.Tensor, ids: torch.Tensor, dst: torch.Tensor) -> to
 def euler_step(sample: torch.Tensor, v: torch.Tensor, dt: float, mask: Optional[torch.Tensor] = None,
                dt_direct: float = 0.0) -> torch.Tensor:
     s, vv = _rows(sample), _rows(v)
+    if mask is not None and (mask.dtype != torch.uint8 or not mask.is_contiguous() or mask.numel() != s.shape[0]):
+        raise _lib.RegionEHipError("euler_step: mask must be uint8 [L] (the third result of arp_partition)")
     out = torch.empty_like(vv)
     rc = _lib.lib().rgn_euler_step(_p(s), _dt(s), _p(vv), _dt(vv), _p(out), _p(mask), float(dt), float(dt_direct),
                                    s.shape[0], s.shape[1], _stream())
@@ -125,6 +127,8 @@ def euler_step(sample: torch.Tensor, v: torch.Tensor, dt: float, mask: Optional[
 def avd_apply(cache: torch.Tensor, ratio: float, ids: Optional[torch.Tensor] = None,
               round_ratio: bool = False) -> torch.Tensor:
     c = _rows(cache)
+    if ids is not None and ids.dtype != torch.int64:
+        raise _lib.RegionEHipError("avd_apply: ids must be int64")        # the kernel reads 8-byte indices
     idv = ids.reshape(-1).contiguous() if ids is not None else None
     K = idv.numel() if idv is not None else c.shape[0]
     out = torch.empty((K, c.shape[1]), dtype=c.dtype, device=c.device)

@@ -150,6 +150,31 @@ def test_torch_ops_equal_ctypes_wrappers():
 
 
 @pytest.mark.gpu
+def test_ops_refuse_arguments_the_kernels_would_misread():
+    """Wrong index / mask dtypes and a KV length past the slab are errors on both registrations, never out-of-bounds reads."""
+    from regione_amd import ops
+    L = 64
+    v = torch.randn(1, L, 64).bfloat16().cuda()
+    s = torch.randn(1, L, 64).cuda()
+    ids32 = torch.arange(8, dtype=torch.int32, device="cuda")[None]
+    with pytest.raises(RuntimeError):
+        torch.ops.regione_mi.avd_apply(v, 1.01, ids32)
+    with pytest.raises(RuntimeError):
+        torch.ops.regione_mi.split_euler_step(s, v, -0.03, torch.ones(L, dtype=torch.bool, device="cuda"), -0.5)
+    with pytest.raises(RuntimeError):
+        torch.ops.regione_mi.split_euler_step(s, v, -0.03, torch.ones(L // 2, dtype=torch.uint8, device="cuda"), -0.5)
+    H, d = 2, 256
+    skv_pad = ops.padded(100)
+    kc = torch.zeros(skv_pad, d, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros(d, skv_pad, dtype=torch.bfloat16, device="cuda")
+    q = torch.zeros(16, d, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):
+        torch.ops.regione_mi.region_attention(q, kc, vc, q, skv_pad + 1, H)
+    torch.ops.regione_mi.region_attention(q, kc, vc, q, 100, H)           # the same call with a valid length runs
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_engine_runs_on_the_registered_op_surface():
     """One toy 28-step RegionE edit under a dispatch recorder: the ops SURVEY.md 8(b) names are the ones the product's
     patch set and attention processors actually dispatch (not a side registration next to a ctypes path)."""
