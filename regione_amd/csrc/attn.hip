@@ -49,7 +49,6 @@ struct AttnArgs {
     // round-aware launch: this launch covers items [item_offset, item_offset + nitems_launch); in
     // SPLIT mode every item is cut into nsplit KV ranges whose partial (O, m, l) go to `ws`.
     int item_offset, nitems_launch, nsplit;
-    int dephase;                 // hand-scheduled loop: 0 = every wave in role A, 1 = waves 4..7 in role B, 2 = odd waves in role B
     // static softmax shift (rgn_attention_bounded): the caller guarantees |q . k| * scale <= bound for every pair, so
     // P = exp2(S * c - static_m) cannot overflow or vanish and the loop keeps no running max (hand-scheduled kernel only)
     int static_on;
@@ -431,9 +430,9 @@ __global__ __launch_bounds__(512, 1) void attention_asm_kernel(const AttnArgs g)
         uint32_t stg_k = __builtin_amdgcn_readfirstlane(lds0 + 32768u), stg_v = __builtin_amdgcn_readfirstlane(lds0), stg_d = stg_v;
         const uint32_t wdst = __builtin_amdgcn_readfirstlane((uint32_t)wave * 2048u);
         uint32_t cnt = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) >> 1), rem = __builtin_amdgcn_readfirstlane((uint32_t)(ntiles - 1) & 1u);
-        // role B = tile barrier between X and Y instead of ahead of X (tools/gen_attn_loop.py:body): the two waves of a SIMD
-        // (wave w and w + 4) take different roles so that their exp-heavy phases alternate
-        const uint32_t role = __builtin_amdgcn_readfirstlane(g.dephase == 1 ? (uint32_t)(wave >> 2) & 1u : g.dephase == 2 ? (uint32_t)wave & 1u : 0u);
+        // every wave in role A: the two-role (dephased) loop of tools/gen_attn_loop.py (ATTN_DEPHASE=1 builds) measured +-0.5 %
+        // and is not shipped (profiles/EXPERIMENTS.md 4.7); the operand stays so that such a build needs no other source change
+        const uint32_t role = __builtin_amdgcn_readfirstlane(0u);
         const float sl2e = g.scale_log2e;
         const uint64_t sl2e2 = ((uint64_t)__float_as_uint(sl2e) << 32) | __float_as_uint(sl2e);    // both halves: packed-fp32 operand
         uint32_t stmp, stmp2, sdst;
@@ -740,7 +739,6 @@ int rgn_attention_bounded(const void* Q, int ldq, const void* k_slab, const void
         g.static_on = (!(e && atoi(e) == 0) && score_bound > 0.0f && b2 <= 96.0f) ? 1 : 0;
         g.static_m = 0.0f;
     }
-    { const char* e = getenv("RGN_ATTN_DEPHASE"); g.dephase = e ? atoi(e) : 0; }   // only meaningful for an ATTN_DEPHASE=1 build of the loop
     hipStream_t st = (hipStream_t)stream;
     // 8-wave workgroups (256 query rows share each K/V tile, 1 per CU) unless the query set is tiny
     int variant = (H * ((Sq + 255) / 256) >= 96) ? 8 : 4;

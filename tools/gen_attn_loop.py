@@ -372,7 +372,7 @@ def body(st, p, full, tag, role="A"):
     start X(t) and the role-B waves have just finished it: behind the barrier A runs X (80 VALU instructions, 2/3 of them
     quarter-rate exp) while B runs Y (61 cheap ones), then the other way round.  Two waves of one SIMD with different roles
     therefore never want the VALU for their exp phases at the same time.  ATTN_DEPHASE=1 (measurement build; the kernel picks the
-    roles with RGN_ATTN_DEPHASE=1: waves 4..7 in role B, =2: odd waves): correct, and within +-0.5 % of the single-role loop on
+    roles, waves 4..7 or the odd waves in role B): correct, and within +-0.5 % of the single-role loop on
     every shape (MI355X) - the waves of a SIMD evidently do not stay phase-locked behind the barrier anyway - so the shipped loop
     has one role.  Ring safety is unchanged: at barrier t every wave has
     finished Y(t-1) (the stage tile t+4 overwrites), and role B's early X(t) reads K(t+1), which landed by barrier t-1."""
