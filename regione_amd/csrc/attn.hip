@@ -524,39 +524,9 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g
     if (qr >= g.Sq) return;
     const float* base = g.ws + (size_t)u * g.nsplit * (size_t)(QB * 130);
     float mstar = -1e30f;
+    for (int s = 0; s < g.nsplit; ++s) mstar = fmaxf(mstar, base[(size_t)s * QB * 130 + QB * 128 + row]);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float l = 0.f;
-    constexpr int MAXS = 8;
-    if (g.nsplit <= MAXS) {
-        // every piece's maximum, row sum and row requested back to back (one global round trip instead of two dependent walks),
-        // merged in piece order with the expressions of the walk below: bit-identical
-        float mv[MAXS], lv[MAXS];
-        float4 xa[MAXS], xb[MAXS];
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            mv[s] = -1e30f; lv[s] = 0.f;
-            xa[s] = make_float4(0.f, 0.f, 0.f, 0.f); xb[s] = xa[s];
-            if (s < g.nsplit) {
-                const float* b = base + (size_t)s * QB * 130;
-                mv[s] = b[QB * 128 + row];
-                lv[s] = b[QB * 129 + row];
-                xa[s] = *(const float4*)(b + (size_t)row * 128 + c);
-                xb[s] = *(const float4*)(b + (size_t)row * 128 + c + 4);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s)
-            if (s < g.nsplit) mstar = fmaxf(mstar, mv[s]);
-#pragma unroll
-        for (int s = 0; s < MAXS; ++s) {
-            if (s >= g.nsplit) continue;
-            const float w = __builtin_amdgcn_exp2f(mv[s] - mstar);
-            l += lv[s] * w;
-            acc[0] += xa[s].x * w; acc[1] += xa[s].y * w; acc[2] += xa[s].z * w; acc[3] += xa[s].w * w;
-            acc[4] += xb[s].x * w; acc[5] += xb[s].y * w; acc[6] += xb[s].z * w; acc[7] += xb[s].w * w;
-        }
-    } else {
-    for (int s = 0; s < g.nsplit; ++s) mstar = fmaxf(mstar, base[(size_t)s * QB * 130 + QB * 128 + row]);
     for (int s = 0; s < g.nsplit; ++s) {
         const float* b = base + (size_t)s * QB * 130;
         const float w = __builtin_amdgcn_exp2f(b[QB * 128 + row] - mstar);
@@ -564,7 +534,6 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const AttnArgs g
         const float4 x0 = *(const float4*)(b + (size_t)row * 128 + c), x1 = *(const float4*)(b + (size_t)row * 128 + c + 4);
         acc[0] += x0.x * w; acc[1] += x0.y * w; acc[2] += x0.z * w; acc[3] += x0.w * w;
         acc[4] += x1.x * w; acc[5] += x1.y * w; acc[6] += x1.z * w; acc[7] += x1.w * w;
-    }
     }
     const float inv = 1.0f / l;
     uint4 out;
@@ -593,49 +562,13 @@ __global__ __launch_bounds__(256) void attention_combine_sk_kernel(const AttnArg
     while (w0 + 1 < G && bound(w0 + 1) <= lo) ++w0;
     while (w0 > 0 && bound(w0) > lo) --w0;
     float mstar = -1e30f;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float l = 0.f;
-    // An item meets 2 ... 4 runs (G / items + 1).  Walking them twice with dependent loads - the maxima, then the rows - made this
-    // pass two chains of global round trips with nothing to overlap them (16 us for 2304 small workgroups): up to MAXR runs are
-    // requested back to back instead, then merged in the same order with the same expressions (bit-identical); more runs than that
-    // (tiny launches) take the walk below.
-    constexpr int MAXR = 6;
-    if (!(w0 + MAXR < G && bound(w0 + MAXR) < hi)) {
-        bool ok[MAXR];
-        float mv[MAXR], lv[MAXR];
-        float4 xa[MAXR], xb[MAXR];
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const int w = w0 + i;
-            ok[i] = w < G && bound(w) < hi && bound(w + 1) > bound(w);
-            mv[i] = -1e30f; lv[i] = 0.f;
-            xa[i] = make_float4(0.f, 0.f, 0.f, 0.f); xb[i] = xa[i];
-            if (ok[i]) {
-                const int sg = ((int)(bound(w) / nt) == u) ? 0 : 1;
-                const float* b = g.ws + ((size_t)w * 2 + sg) * (size_t)(QB * 130);
-                mv[i] = b[QB * 128 + row];
-                lv[i] = b[QB * 129 + row];
-                xa[i] = *(const float4*)(b + (size_t)row * 128 + c);
-                xb[i] = *(const float4*)(b + (size_t)row * 128 + c + 4);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i)
-            if (ok[i]) mstar = fmaxf(mstar, mv[i]);
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            if (!ok[i]) continue;
-            const float wt = __builtin_amdgcn_exp2f(mv[i] - mstar);
-            l += lv[i] * wt;
-            acc[0] += xa[i].x * wt; acc[1] += xa[i].y * wt; acc[2] += xa[i].z * wt; acc[3] += xa[i].w * wt;
-            acc[4] += xb[i].x * wt; acc[5] += xb[i].y * wt; acc[6] += xb[i].z * wt; acc[7] += xb[i].w * wt;
-        }
-    } else {
     for (int w = w0; w < G && bound(w) < hi; ++w) {
         if (bound(w + 1) <= bound(w)) continue;                                  // empty run
         const int sg = ((int)(bound(w) / nt) == u) ? 0 : 1;
         mstar = fmaxf(mstar, g.ws[((size_t)w * 2 + sg) * (size_t)(QB * 130) + QB * 128 + row]);
     }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float l = 0.f;
     for (int w = w0; w < G && bound(w) < hi; ++w) {
         if (bound(w + 1) <= bound(w)) continue;
         const int sg = ((int)(bound(w) / nt) == u) ? 0 : 1;
@@ -645,7 +578,6 @@ __global__ __launch_bounds__(256) void attention_combine_sk_kernel(const AttnArg
         const float4 x0 = *(const float4*)(b + (size_t)row * 128 + c), x1 = *(const float4*)(b + (size_t)row * 128 + c + 4);
         acc[0] += x0.x * wt; acc[1] += x0.y * wt; acc[2] += x0.z * wt; acc[3] += x0.w * wt;
         acc[4] += x1.x * wt; acc[5] += x1.y * wt; acc[6] += x1.z * wt; acc[7] += x1.w * wt;
-    }
     }
     const float inv = 1.0f / l;
     uint4 out;
