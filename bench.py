@@ -38,6 +38,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 N_STEPS = 28
+# counter summaries of THIS command under rocprofv3 --pmc (tools/probes/measure_counters.sh); quoted only when their csrc_sha16 is the
+# hash of the kernel sources this process runs (load_stamped)
+PMC_TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_MFMA_FILE = "profiles/r05_pmc_mfma.json"
+PARITY_FILES = ("profiles/r05_parity_headline.json", "profiles/r05_parity_full_depth.json")
 
 
 def algorithmic_flops(cfg, T, N, K_e):
@@ -83,25 +88,30 @@ class KernelTimer:
             s.record()
             r = timer._orig_group(problems, **kw)
             e.record()
-            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * sum(ms) * N * K))
+            nw = len({p.W.data_ptr() for p in ps})
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * sum(ms) * N * K, gemm_bytes(sum(ms), N, K, nw, ps[0].W)))
             timer.shapes.setdefault((sum(ms[0::2]), sum(ms[1::2]), N, K), []).append((s, e))
             return r
 
-        def timed_gemm(fn, m0, m1, N, K, *a, **kw):
+        def gemm_bytes(m, N, K, n_weights, W):
+            """Algorithmic operand bytes of one op launch: A once + every distinct W once + C once (bf16; fp8 W one byte)."""
+            return 2.0 * m * K + float(n_weights) * N * K * W.element_size() + 2.0 * m * N
+
+        def timed_gemm(fn, m0, m1, N, K, *a, W=None, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **kw)
             e.record()
-            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (m0 + m1) * N * K))
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (m0 + m1) * N * K, gemm_bytes(m0 + m1, N, K, 2 if m1 else 1, W)))
             timer.shapes.setdefault((m0, m1, N, K), []).append((s, e))
             return r
 
         def gemm_qkv(A, W, bias, out, epi, **kw):          # fused Q/K/V epilogue: same FLOPs, epilogue work included
-            return timed_gemm(timer._orig_qkv, A.shape[0], 0, W.shape[0], A.shape[1], A, W, bias, out, epi, **kw)
+            return timed_gemm(timer._orig_qkv, A.shape[0], 0, W.shape[0], A.shape[1], A, W, bias, out, epi, W=W, **kw)
 
         def gemm_qkv_pair(A0, W0, b0, o0, e0, A1, W1, b1, o1, e1):
             return timed_gemm(timer._orig_qkv_pair, A0.shape[0], A1.shape[0], W0.shape[0], W0.shape[1],
-                              A0, W0, b0, o0, e0, A1, W1, b1, o1, e1)
+                              A0, W0, b0, o0, e0, A1, W1, b1, o1, e1, W=W0)
 
         def gemm_pair(A0, W0, b0, o0, A1, W1, b1, o1, **kw):
             N, K = W0.shape
@@ -109,7 +119,8 @@ class KernelTimer:
             s.record()
             r = timer._orig_pair(A0, W0, b0, o0, A1, W1, b1, o1, **kw)
             e.record()
-            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (A0.shape[0] + A1.shape[0]) * N * K))
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * (A0.shape[0] + A1.shape[0]) * N * K,
+                                                                 gemm_bytes(A0.shape[0] + A1.shape[0], N, K, 2, W0)))
             timer.shapes.setdefault((A0.shape[0], A1.shape[0], N, K), []).append((s, e))
             return r
 
@@ -120,7 +131,7 @@ class KernelTimer:
             s.record()
             r = timer._orig_gemm(A, W, bias, out, **kw)
             e.record()
-            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * M * N * K))
+            timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * M * N * K, gemm_bytes(M, N, K, 1, W)))
             timer.shapes.setdefault((M, 0, N, K), []).append((s, e))
             return r
 
@@ -129,10 +140,14 @@ class KernelTimer:
             s.record()
             r = timer._orig_attn(q, k_slab, vt_slab, out, skv, H, scale, workspace, score_bound)
             e.record()
-            timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * H * 128))
+            timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * H * 128, attn_bytes(q.shape[0], skv, H)))
             if q.shape[0] < skv:             # region step: the K / V^T cache slabs are streamed once per launch
-                timer.rec.setdefault("_region_attention_kv", []).append((s, e, 2.0 * skv * H * 128 * 2))
+                timer.rec.setdefault("_region_attention_kv", []).append((s, e, 2.0 * skv * H * 128 * 2, 0.0))
             return r
+
+        def attn_bytes(sq, skv, H):
+            """Q read + O written + the K and V^T slabs read once (bf16)."""
+            return 2.0 * (2.0 * sq + 2.0 * skv) * H * 128
 
         ops.gemm, ops.attention, ops.gemm_pair = gemm, attention, gemm_pair
         ops.gemm_qkv, ops.gemm_qkv_pair = gemm_qkv, gemm_qkv_pair
@@ -146,11 +161,11 @@ class KernelTimer:
             o_kv, o_pair, o_group, o_attn = R.kv_partial_update_, R.kv_partial_update_pair_, R.kv_partial_update_group_, R.region_attention
 
             def r_kv(x, w, *a, **kw):
-                return timed_gemm(o_kv, x.shape[0], 0, w.shape[0], x.shape[1], x, w, *a, **kw)
+                return timed_gemm(o_kv, x.shape[0], 0, w.shape[0], x.shape[1], x, w, *a, W=w, **kw)
 
             def r_pair(x_img, w_img, b_img, out_img, nq, nk, x_txt, *a, **kw):
                 return timed_gemm(o_pair, x_img.shape[0], x_txt.shape[0], w_img.shape[0], w_img.shape[1],
-                                  x_img, w_img, b_img, out_img, nq, nk, x_txt, *a, **kw)
+                                  x_img, w_img, b_img, out_img, nq, nk, x_txt, *a, W=w_img, **kw)
 
             def r_group(x, w_kvq, *a, **kw):
                 ms = [t.shape[0] for t in x]
@@ -159,7 +174,8 @@ class KernelTimer:
                 s.record()
                 r = o_group(x, w_kvq, *a, **kw)
                 e.record()
-                timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * sum(ms) * N * K))
+                timer.rec.setdefault("gemm_bf16_kernel", []).append((s, e, 2.0 * sum(ms) * N * K,
+                                                                     gemm_bytes(sum(ms), N, K, len({t.data_ptr() for t in w_kvq}), w_kvq[0])))
                 timer.shapes.setdefault((sum(ms[0::2]), sum(ms[1::2]), N, K), []).append((s, e))
                 return r
 
@@ -168,22 +184,20 @@ class KernelTimer:
                 s.record()
                 r = o_attn(q, k_cache, vt_cache, out, skv, heads, *a, **kw)
                 e.record()
-                timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * heads * 128))
+                timer.rec.setdefault("attention_kernel", []).append((s, e, 4.0 * q.shape[0] * skv * heads * 128, attn_bytes(q.shape[0], skv, heads)))
                 if q.shape[0] < skv:
-                    timer.rec.setdefault("_region_attention_kv", []).append((s, e, 2.0 * skv * heads * 128 * 2))
+                    timer.rec.setdefault("_region_attention_kv", []).append((s, e, 2.0 * skv * heads * 128 * 2, 0.0))
                 return r
             R.kv_partial_update_, R.kv_partial_update_pair_, R.kv_partial_update_group_, R.region_attention = r_kv, r_pair, r_group, r_attn
         # per-launch durations need launches that do not share the chip: the batched CFG pass keeps both branches' attention on
         # one stream while the timer is installed (the throughput legs run without the timer and with the default)
-        self._prev_streams = os.environ.get("RGN_ATTN_BRANCH_STREAMS")
-        os.environ["RGN_ATTN_BRANCH_STREAMS"] = "0"
+        from regione_amd.harness import flux as HF
+        self._prev_streams, HF.ATTN_BRANCH_STREAMS = HF.ATTN_BRANCH_STREAMS, False
 
     def unwrap(self):
         import regione_amd.ops as ops
-        if self._prev_streams is None:
-            os.environ.pop("RGN_ATTN_BRANCH_STREAMS", None)
-        else:
-            os.environ["RGN_ATTN_BRANCH_STREAMS"] = self._prev_streams
+        from regione_amd.harness import flux as HF
+        HF.ATTN_BRANCH_STREAMS = self._prev_streams
         ops.gemm, ops.attention, ops.gemm_pair = self._orig_gemm, self._orig_attn, self._orig_pair
         ops.gemm_qkv, ops.gemm_qkv_pair = self._orig_qkv, self._orig_qkv_pair
         ops.gemm_group = self._orig_group
@@ -197,10 +211,10 @@ class KernelTimer:
         for name, lst in self.rec.items():
             if name.startswith("_"):
                 continue
-            ms = sum(s.elapsed_time(e) for s, e, _ in lst)
-            fl = sum(f for _, _, f in lst)
+            ms = sum(s.elapsed_time(e) for s, e, _, _ in lst)
+            fl = sum(f for _, _, f, _ in lst)
             out[name] = dict(launches=len(lst), total_ms=ms, avg_us=1e3 * ms / len(lst), flops_per_launch=fl / len(lst),
-                             achieved_tflops=fl / (ms * 1e-3) / 1e12)
+                             achieved_tflops=fl / (ms * 1e-3) / 1e12, algorithmic_bytes_per_launch=sum(b for _, _, _, b in lst) / len(lst))
         return out
 
     def region_kv_read(self):
@@ -210,9 +224,9 @@ class KernelTimer:
         lst = self.rec.get("_region_attention_kv", [])
         if not lst:
             return None
-        ms = sum(s.elapsed_time(e) for s, e, _ in lst)
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in lst)
         return dict(launches=len(lst), bytes_per_launch=lst[0][2], avg_launch_us=1e3 * ms / len(lst),
-                    achieved_gbs=sum(b for _, _, b in lst) / (ms * 1e-3) / 1e9, peak_gbs=8000.0)
+                    achieved_gbs=sum(b for _, _, b, _ in lst) / (ms * 1e-3) / 1e9, peak_gbs=8000.0)
 
 
 def physical_cores():
@@ -240,6 +254,15 @@ def csrc_hash():
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def load_stamped(rel_path, stamp=None):
+    """A committed counter summary, or {} when it is missing or was measured on other kernel sources than the ones running."""
+    try:
+        d = json.load(open(os.path.join(ROOT, rel_path)))
+    except (OSError, ValueError):
+        return {}
+    return d if d.get("csrc_sha16") == (stamp or csrc_hash()) else {}
 
 
 def build_pipeline(cfg, device, seed):
@@ -376,6 +399,8 @@ def main():
                          "`--gpus 8 --true-cfg 6.0` is BASELINE.json configs[3]")
     ap.add_argument("--toy", action="store_true", help="toy model (debugging only; result is not a valid bench line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-5pct", action="store_true", help="profiling runs: skip the untimed K_e = 5 %% leg")
+    ap.add_argument("--no-ktimer", action="store_true", help="profiling runs: no per-launch HIP events (drops the roofline objects)")
     ap.add_argument("--no-vanilla", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="debugging: 'gloo' lets several ranks share ONE GPU (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="debugging: every rank uses cuda:0 (single-GPU box smoke of the multi-rank path)")
@@ -469,7 +494,7 @@ def main():
             # per-launch HIP events cost ~1.3 % of an edit (two marker packets around each of ~900 launches), so only
             # the LAST timed edit carries them: the roofline figures come from inside the timed region, the headline
             # number is not paying for its own instrumentation on the other edits
-            instrument = (k == args.steps - 1) and not os.environ.get("RGN_BENCH_NO_KTIMER")
+            instrument = (k == args.steps - 1) and not args.no_ktimer
             if instrument:
                 timer.wrap(ops)
             if world > 1:
@@ -529,31 +554,31 @@ def main():
         result["per_rank"] = per_rank          # K_e imbalance between images = the path's only scaling loss
     if dist is not None:
         result["collectives"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "forced_in_world_of_one": bool(force)}
-    # PMC passes cannot run inside the timed region (counter collection serialises kernels): the per-launch HBM-side
-    # traffic comes from a separate rocprofv3 --pmc run of THIS command (tools/pmc_traffic.py -> profiles/r03_pmc_traffic.json),
-    # quoted only when that file was measured on the same kernel sources (csrc_sha16); otherwise null
-    pmc, pmc_file = {}, "profiles/r04_pmc_traffic.json"
-    busy, busy_file = {}, "profiles/r04_pmc_mfma.json"       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel family
-    try:
-        pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-        if pmc.get("csrc_sha16") != csrc_hash():
-            pmc = {}
-    except (OSError, ValueError):
-        pmc = {}
-    try:
-        busy = json.load(open(os.path.join(ROOT, busy_file)))
-        if busy.get("csrc_sha16") != csrc_hash():
-            busy = {}
-    except (OSError, ValueError):
-        busy = {}
+    # PMC passes cannot run inside the timed region (counter collection serialises kernels): fabric traffic and MFMA-busy come from
+    # separate rocprofv3 --pmc runs of THIS command (tools/pmc_traffic.py / pmc_summary.py), quoted only when those files were measured
+    # on the same kernel sources (csrc_sha16); otherwise null.  The counters tally kernel DISPATCHES (an op launch = whole rounds +
+    # remainder pieces + a reduce / merge pass); `traffic` here is per OP LAUNCH = the family's bytes per edit / the op launches per
+    # edit, so that it sits beside `flops_per_launch` and `algorithmic_bytes_per_launch` in the same unit (verdict r4, weak #6).
+    pmc, busy = load_stamped(PMC_TRAFFIC_FILE), load_stamped(PMC_MFMA_FILE)
+
+    def traffic_fields(family, k):
+        t = pmc.get(family, {})
+        per_edit = t.get("traffic_bytes_per_edit")
+        alg = k["algorithmic_bytes_per_launch"]
+        per_launch = per_edit / k["launches"] if per_edit else None
+        return {"traffic": per_launch, "algorithmic_bytes_per_launch": alg,
+                "traffic_vs_algorithmic": (per_launch / alg) if per_launch else None,
+                "traffic_unit": (f"bytes per OP LAUNCH = L2<-fabric reads (x2-corrected, Infinity-Cache hits included) + WRITE_SIZE of every "
+                                 f"dispatch of the family in one edit / op launches per edit ({PMC_TRAFFIC_FILE}, same csrc_sha16; "
+                                 f"{t.get('dispatches_per_edit')} dispatches per edit for {k['launches']} op launches: dispatches != launches)"),
+                "hbm_side": t.get("hbm_side")}
     if "gemm_bf16_kernel" in ksum:
         k = ksum["gemm_bf16_kernel"]
         result["roofline"] = {"bound": "mfma", "kernel": "gemm_bf16_kernel", "achieved": k["achieved_tflops"],
                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
-                              "traffic": pmc.get("gemm_bf16_kernel", {}).get("traffic_bytes_per_launch"),
-                              "traffic_unit": f"bytes/launch (L2<-fabric reads x2-corrected + WRITE_SIZE, {pmc_file}, same csrc_sha16)",
+                              **traffic_fields("gemm_bf16_kernel", k),
                               "mfma_busy": busy.get("ALL gemm_bf16_kernel", {}).get("mfma_util"),
-                              "mfma_busy_unit": f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), {busy_file}, same csrc_sha16",
+                              "mfma_busy_unit": f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), {PMC_MFMA_FILE}, same csrc_sha16",
                               "launches": k["launches"], "avg_launch_us": k["avg_us"],
                               "flops_per_launch": k["flops_per_launch"], "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
     result["gemm_shapes"] = timer.shape_table()
@@ -561,15 +586,15 @@ def main():
         k = ksum["attention_kernel"]
         result["roofline_attention"] = {"bound": "mfma", "kernel": "attention_asm_kernel (+ attention_kernel for ragged KV lengths)", "achieved": k["achieved_tflops"],
                                         "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": k["achieved_tflops"] / PEAK_BF16_TFLOPS,
-                                        "traffic": pmc.get("attention_kernel", {}).get("traffic_bytes_per_launch"),
+                                        **traffic_fields("attention_kernel", k),
                                         "mfma_busy": busy.get("ALL attention_kernel", {}).get("mfma_util"),
-                                        "launches": k["launches"], "avg_launch_us": k["avg_us"],
+                                        "launches": k["launches"], "avg_launch_us": k["avg_us"], "flops_per_launch": k["flops_per_launch"],
                                         "share_of_edit_time": k["total_ms"] * 1e-3 / edit_s}
 
     kv = timer.region_kv_read()
     if kv is not None:
         result["region_attention_kv_read"] = kv
-    if rank == 0 and world == 1 and not args.toy and not os.environ.get("RGN_BENCH_NO_5PCT"):
+    if rank == 0 and world == 1 and not args.toy and not args.no_5pct:
         # untimed extra leg: the same edit with K_e = 5 % of the tokens - the case where the region-step attention launch is
         # bound by the K / V^T cache read rather than by MFMA ("KV-read HBM GB/s in region attention")
         side5 = int(round((0.05 * L) ** 0.5))

@@ -32,8 +32,22 @@ extern "C" {
 #define RGN_E_BADARG (-1)
 #define RGN_E_UNSUPPORTED (-2)
 
+/* Bumped whenever a struct layout or a signature of this header changes.  rgn_version() returns the value the LIBRARY was built
+ * with, rgn_abi_struct_bytes() = sizeof(rgn_qkv_epilogue) * 1000 + sizeof(rgn_gemm_problem) as the library sees them: a binding
+ * compiled against another header (a stale libregione_torch.so next to a rebuilt libregione_hip.so) compares both at load time
+ * and refuses to run instead of misreading structs passed by pointer. */
+#define RGN_ABI_VERSION 105
 int rgn_version(void);
+size_t rgn_abi_struct_bytes(void);
 const char* rgn_last_error(void);
+/* Launch-plan override: the library's one test / measurement hook (no reference counterpart).  Every knob is -1 (= the launch cost
+ * models decide) in a shipped run.  `key` in {gemm_pieces (1 = one plain launch, n >= 2 = n K pieces of a round's remainder),
+ * gemm_geometry (128 | 256), gemm_asm (0 = compiler-scheduled kernels only), gemm_quarter (0 never | 1 always), attn_waves (4 | 8),
+ * attn_split (0 = never cut KV), attn_streamk (0 = equal pieces only | 1 = wherever possible), attn_asm (0 = compiler-scheduled
+ * loop)}; value -1 restores the default; key NULL resets every knob.  Process-wide, not synchronised with launches in flight on other
+ * threads.  The same knobs can be preset once per process with RGN_PLAN_OVERRIDE="key=value,key=value" - the only environment
+ * variable libregione_hip.so reads, at the first launch.  Results never depend on a knob beyond fp32 summation order. */
+int rgn_plan_override(const char* key, int value);
 /* The launch plan the GEMM planner chose for the last rgn_gemm_* call on this thread (introspection for tests and traces; the
  * reference has no counterpart): bits 0-7 = K pieces of the remainder (1 = none), bit 8 = quarter-tile remainder, bit 10 =
  * 256 x 256 tile geometry. */

@@ -44,6 +44,8 @@ _prob_p = C.POINTER(GemmProblem)
 # name -> argtypes (restype is always int unless listed in _RESTYPE)
 SIGNATURES = {
     "rgn_version": [],
+    "rgn_abi_struct_bytes": [],
+    "rgn_plan_override": [C.c_char_p, _c_int],
     "rgn_gemm_last_plan": [],
     "rgn_attention_last_plan": [],
     "rgn_attention_plan_query": [_c_int, _c_int, _c_int, C.c_size_t],
@@ -100,7 +102,7 @@ SIGNATURES = {
                               _c_float, _c_float, _c_void_p, C.c_size_t, _c_void_p],
     "rgn_attention_workspace_bytes": [_c_int, _c_int],
 }
-_RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_attention_workspace_bytes": C.c_size_t,
+_RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_abi_struct_bytes": C.c_size_t, "rgn_attention_workspace_bytes": C.c_size_t,
             "rgn_gemm_workspace_bytes": C.c_size_t}
 
 _lib = None
@@ -124,8 +126,34 @@ def lib():
         fn = getattr(h, name)           # AttributeError if the symbol is missing: loud by design
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
+    # the ctypes mirrors of the structs passed by pointer must be the library's layout (a library built from another header)
+    want = C.sizeof(QkvEpilogue) * 1000 + C.sizeof(GemmProblem)
+    if h.rgn_abi_struct_bytes() != want:
+        raise RegionEHipError(f"{LIB_PATH}: struct layout {h.rgn_abi_struct_bytes()} != the Python binding's {want} "
+                              f"(library ABI version {h.rgn_version()}): rebuild with `python -m regione_amd.build --force`")
     _lib = h
     return h
+
+
+import contextlib as _contextlib
+
+PLAN_KEYS = ("gemm_pieces", "gemm_geometry", "gemm_asm", "gemm_quarter", "attn_waves", "attn_split", "attn_streamk", "attn_asm")
+
+
+@_contextlib.contextmanager
+def plan_override(**knobs):
+    """Force launch-plan knobs for the duration of a `with` block (rgn_plan_override, include/regione_hip.h) - tests and sweep
+    tools only; every knob returns to -1 (= the cost models decide) on exit.
+
+        with _lib.plan_override(gemm_pieces=3, gemm_geometry=256): ops.gemm(...)"""
+    h = lib()
+    for k, v in knobs.items():
+        check(h.rgn_plan_override(k.encode(), int(v)), f"rgn_plan_override({k})")
+    try:
+        yield
+    finally:
+        for k in knobs:
+            h.rgn_plan_override(k.encode(), -1)
 
 
 def check(rc: int, what: str = ""):

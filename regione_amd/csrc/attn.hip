@@ -25,7 +25,7 @@
 // MFMA S(t+1) = K(t+1) Q^T under the exp2 / bf16 packing of P(t), MFMA O += V^T(t) P(t)^T under the row sums and the max of
 // S(t+1) - over a five-stage LDS-DMA ring; <1> = equal KV split pieces, <2> = stream-K runs of the flattened (item, KV tile)
 // steps for remainders (attention_schedule picks per launch; partials merged by attention_combine[_sk]_kernel).
-// `attention_kernel` (compiler-scheduled, 4 or 8 waves): ragged KV lengths, tiny query sets, RGN_ATTN_ASM=0.
+// `attention_kernel` (compiler-scheduled, 4 or 8 waves): ragged KV lengths, tiny query sets.
 #include "common.h"
 #include <stdlib.h>
 #include <utility>
@@ -604,10 +604,9 @@ static int launch_attention_asm(const AttnArgs& g, int nblocks, hipStream_t st) 
     return check_launch("attention_asm_kernel");
 }
 
-// RGN_ATTN_ASM=0: A/B switch back to the compiler-scheduled loop.  The asm loop needs whole KV tiles and 32-bit slab offsets.
+// The asm loop needs whole KV tiles and 32-bit slab offsets (plan_override().attn_asm = 0: the compiler-scheduled loop everywhere - tests).
 static bool attention_use_asm(const AttnArgs& g) {
-    static const int on = [] { const char* e = getenv("RGN_ATTN_ASM"); return e ? atoi(e) : 1; }();
-    return on && (g.Skv % KV_T) == 0 && (size_t)g.skv_pad * g.H * 256 < ((size_t)1 << 32);
+    return plan_override().attn_asm != 0 && (g.Skv % KV_T) == 0 && (size_t)g.skv_pad * g.H * 256 < ((size_t)1 << 32);
 }
 
 template <int NW, int NSTAGE, bool SPLIT>
@@ -665,13 +664,13 @@ static int attention_schedule(AttnArgs g, int slots, void* ws, size_t ws_bytes, 
         // stream-K (asm kernel): `slots` equal runs of the flattened (item, KV tile) steps instead of S equal pieces per item -
         // every CU gets the same number of steps whatever left / slots is, in ONE round, and the launch leaves at most
         // left + slots partials instead of left x S; a run that crosses an item boundary pays the piece cost twice.
-        // RGN_ATTN_STREAMK=0: A/B switch back to the equal split; =2: stream-K wherever it is possible.
-        const char* sk_env = getenv("RGN_ATTN_STREAMK");
+        // plan_override().attn_streamk: 0 = equal split only, 1 = stream-K wherever it is possible (tests, sweeps).
+        const int sk_o = plan_override().attn_streamk;
         const long long steps = (long long)left * ntiles;
-        if (NW == 8 && (sk_env ? atoi(sk_env) : 1) && attention_use_asm(g) && left < slots && steps >= 8LL * slots &&
+        if (NW == 8 && sk_o != 0 && attention_use_asm(g) && left < slots && steps >= 8LL * slots &&
             (size_t)slots * 2 * QB * 130 * sizeof(float) <= ws_bytes) {
             const float cost = (float)((steps + slots - 1) / slots) * c_t + 2.0f * c_p + c_m;
-            if (cost < best_cost - 1e-3f || atoi(sk_env ? sk_env : "1") == 2) { best_cost = cost; stream_k = true; }   // 2: forced (tests)
+            if (cost < best_cost - 1e-3f || sk_o == 1) { best_cost = cost; stream_k = true; }   // 1: forced (tests)
         }
     }
     g_last_attn_plan = (stream_k ? 1 : best) | (stream_k ? 0x10 : 0) | (NW == 8 ? 0x20 : 0);
@@ -732,19 +731,18 @@ int rgn_attention_bounded(const void* Q, int ldq, const void* k_slab, const void
     g.scale_log2e = scale * 1.4426950408889634f;
     g.item_offset = 0; g.nitems_launch = 0; g.nsplit = 1; g.ws = nullptr;
     // static softmax shift: with |scores| <= score_bound, exp2(s * log2e) stays within 2^+-96 for score_bound * log2e <= 96 - row
-    // sums over any Skv < 2^31 and the PV accumulators stay far inside fp32 (and bf16 for P).  RGN_ATTN_STATIC_MAX=0: A/B switch.
+    // sums over any Skv < 2^31 and the PV accumulators stay far inside fp32 (and bf16 for P).  score_bound = 0: the running-max loop.
     {
-        const char* e = getenv("RGN_ATTN_STATIC_MAX");
         const float b2 = score_bound * 1.4426950408889634f;
-        g.static_on = (!(e && atoi(e) == 0) && score_bound > 0.0f && b2 <= 96.0f) ? 1 : 0;
+        g.static_on = (score_bound > 0.0f && b2 <= 96.0f) ? 1 : 0;
         g.static_m = 0.0f;
     }
     hipStream_t st = (hipStream_t)stream;
     // 8-wave workgroups (256 query rows share each K/V tile, 1 per CU) unless the query set is tiny
     int variant = (H * ((Sq + 255) / 256) >= 96) ? 8 : 4;
-    const char* v = getenv("RGN_ATTN_VARIANT");
-    if (v && (v[0] == '4' || v[0] == '8')) variant = v[0] - '0';
-    if (v && v[1] == 'n') { workspace = nullptr; workspace_bytes = 0; }        // "8n" / "4n": no KV split
+    const PlanOverride& ov = plan_override();
+    if (ov.attn_waves == 4 || ov.attn_waves == 8) variant = ov.attn_waves;
+    if (ov.attn_split == 0) { workspace = nullptr; workspace_bytes = 0; }        // no KV split
     if (variant == 8) return attention_schedule<8, 3>(g, 256, workspace, workspace_bytes, st);
     return attention_schedule<4, 2>(g, 512, workspace, workspace_bytes, st);
 }
@@ -756,9 +754,9 @@ int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes) {
     AttnArgs g{};
     g.Sq = Sq; g.Skv = Skv; g.H = H; g.skv_pad = (Skv + 63) / 64 * 64;
     int variant = (H * ((Sq + 255) / 256) >= 96) ? 8 : 4;
-    const char* v = getenv("RGN_ATTN_VARIANT");
-    if (v && (v[0] == '4' || v[0] == '8')) variant = v[0] - '0';
-    void* ws = (workspace_bytes > 0 && !(v && v[1] == 'n')) ? (void*)(uintptr_t)64 : nullptr;      // never dereferenced in a dry run
+    const PlanOverride& ov = plan_override();
+    if (ov.attn_waves == 4 || ov.attn_waves == 8) variant = ov.attn_waves;
+    void* ws = (workspace_bytes > 0 && ov.attn_split != 0) ? (void*)(uintptr_t)64 : nullptr;      // never dereferenced in a dry run
     if (variant == 8) (void)attention_schedule<8, 3>(g, 256, ws, ws ? workspace_bytes : 0, nullptr, true);
     else (void)attention_schedule<4, 2>(g, 512, ws, ws ? workspace_bytes : 0, nullptr, true);
     return g_last_attn_plan;

@@ -43,6 +43,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Launch-plan overrides: the library's ONE measurement / test hook (rgn_plan_override in include/regione_hip.h).  Every field is
+// -1 in a shipped run (= the cost models decide); tests and the sweep tools force a schedule to reach paths a small problem would
+// not take by itself, or to time a schedule the planner rejected.  Set through rgn_plan_override(key, value) or, once per process,
+// RGN_PLAN_OVERRIDE="key=value,key=value" (parsed at the first launch: no getenv on the launch path).
+struct PlanOverride {
+    int gemm_pieces;      // K pieces of a round's remainder: 1 = one plain launch (no cut, no quarter tiles), n >= 2 = n pieces
+    int gemm_geometry;    // 128 | 256: tile geometry
+    int gemm_asm;         // 0 = compiler-scheduled kernels only (the fallback of operands >= 4 GiB / K < 128 / short fp8 K)
+    int gemm_quarter;     // 0 = never, 1 = the remainder always as quarter tiles on the 128 geometry
+    int attn_waves;       // 4 | 8 waves per workgroup
+    int attn_split;       // 0 = never cut the KV range of remainder items
+    int attn_streamk;     // 0 = equal KV pieces only, 1 = stream-K wherever it is possible
+    int attn_asm;         // 0 = the compiler-scheduled KV loop (the ragged-KV fallback)
+};
+PlanOverride& plan_override();          // region.hip
+
 typedef __attribute__((ext_vector_type(8))) short bf16x8;    // 8 bf16 = 4 VGPRs (MFMA A/B fragment)
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;

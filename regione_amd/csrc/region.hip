@@ -2,6 +2,8 @@
 // step, Adaptive-Velocity-Decay cache hit.  HBM-streaming, O(L*64) bytes: latency-bound, so the
 // design goal is FEW launches and zero host syncs, with bit-exact rounding vs the reference.
 #include "common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace rgn {
 
@@ -308,13 +310,50 @@ static int launch_morph(const uint8_t* raw, int H, int W, int ed, int64_t* e, in
     return check_launch("arp_morph_compact_kernel");
 }
 
+// the launch-plan override table (common.h): all -1 unless RGN_PLAN_OVERRIDE="key=value,..." names fields - the library's only
+// environment read, once per process
+static bool plan_set(PlanOverride& o, const char* key, int value) {
+    struct { const char* name; int* field; } tab[] = {
+        {"gemm_pieces", &o.gemm_pieces}, {"gemm_geometry", &o.gemm_geometry}, {"gemm_asm", &o.gemm_asm}, {"gemm_quarter", &o.gemm_quarter},
+        {"attn_waves", &o.attn_waves}, {"attn_split", &o.attn_split}, {"attn_streamk", &o.attn_streamk}, {"attn_asm", &o.attn_asm}};
+    for (auto& t : tab)
+        if (strcmp(t.name, key) == 0) { *t.field = value; return true; }
+    return false;
+}
+
+PlanOverride& plan_override() {
+    static PlanOverride o = [] {
+        PlanOverride v{-1, -1, -1, -1, -1, -1, -1, -1};
+        const char* e = getenv("RGN_PLAN_OVERRIDE");
+        if (e != nullptr) {
+            char buf[256];
+            snprintf(buf, sizeof(buf), "%s", e);
+            char* save = nullptr;
+            for (char* tok = strtok_r(buf, ",", &save); tok != nullptr; tok = strtok_r(nullptr, ",", &save)) {
+                char* eq = strchr(tok, '=');
+                if (eq != nullptr) *eq = 0;
+                if (eq == nullptr || !plan_set(v, tok, atoi(eq + 1))) fprintf(stderr, "regione_hip: RGN_PLAN_OVERRIDE: bad entry '%s'\n", tok);
+            }
+        }
+        return v;
+    }();
+    return o;
+}
+
 }  // namespace rgn
 
 using namespace rgn;
 
 extern "C" {
 
-int rgn_version(void) { return 100; }
+int rgn_version(void) { return RGN_ABI_VERSION; }
+size_t rgn_abi_struct_bytes(void) { return sizeof(rgn_qkv_epilogue) * 1000 + sizeof(rgn_gemm_problem); }
+
+int rgn_plan_override(const char* key, int value) {
+    PlanOverride& o = plan_override();
+    if (key == nullptr) { o = PlanOverride{-1, -1, -1, -1, -1, -1, -1, -1}; return 0; }
+    return plan_set(o, key, value) ? 0 : fail(RGN_E_BADARG, "plan_override: unknown key");
+}
 const char* rgn_last_error(void) { return g_err; }
 
 int rgn_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes) {

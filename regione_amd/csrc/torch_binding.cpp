@@ -107,7 +107,8 @@ std::tuple<Tensor, Tensor, Tensor> arp_partition(const Tensor& sample, const Opt
     OptTensor mo;
     if (model_output.has_value() && model_output->defined()) mo = rows(*model_output);
     const int64_t L = s.size(0), D = s.size(1);
-    TORCH_CHECK(c.size(0) == L && c.size(1) == D && h_tok * w_tok == L, "arp_partition: shapes");
+    TORCH_CHECK(c.size(0) == L && c.size(1) == D && h_tok * w_tok == L && c.device() == s.device(), "arp_partition: sample / cond [L, D] with L = h_tok * w_tok, one device");
+    TORCH_CHECK(!mo || (mo->size(0) == L && mo->size(1) == D && mo->device() == s.device()), "arp_partition: model_output must be [L, D] like the sample");
     auto i64 = s.options().dtype(at::kLong), u8 = s.options().dtype(at::kByte);
     Tensor e = at::empty({L}, i64), u = at::empty({L}, i64), raw = at::empty({L}, u8), mask = at::empty({L}, u8);
     Tensor cnt = at::empty({1}, s.options().dtype(at::kInt));
@@ -123,7 +124,7 @@ std::tuple<Tensor, Tensor, Tensor> arp_partition(const Tensor& sample, const Opt
 Tensor gather_rows(const Tensor& x, const Tensor& ids) {
     RGN_DEVICE_GUARD(x);
     Tensor src = rows(x), idv = ids.reshape({-1}).contiguous();
-    TORCH_CHECK(idv.scalar_type() == at::kLong, "gather_rows: ids must be int64");
+    TORCH_CHECK(idv.scalar_type() == at::kLong && idv.device() == src.device(), "gather_rows: ids must be int64 on the source's device");
     Tensor out = at::empty({idv.numel(), src.size(1)}, src.options());
     check_rc(rgn_gather_rows(ptr(src), (const int64_t*)ptr(idv), out.data_ptr(), (int)idv.numel(),
                              (int)(src.size(1) * src.element_size()), stream_of(src)), "rgn_gather_rows");
@@ -133,7 +134,9 @@ Tensor gather_rows(const Tensor& x, const Tensor& ids) {
 void scatter_rows_(const Tensor& src, const Tensor& ids, Tensor dst) {
     RGN_DEVICE_GUARD(src);
     Tensor s = rows(src), d = rows(dst), idv = ids.reshape({-1}).contiguous();
-    TORCH_CHECK(idv.scalar_type() == at::kLong && s.size(1) == d.size(1) && s.scalar_type() == d.scalar_type(), "scatter_rows_: arguments");
+    TORCH_CHECK(idv.scalar_type() == at::kLong && s.size(1) == d.size(1) && s.scalar_type() == d.scalar_type() && idv.device() == s.device() &&
+                    d.device() == s.device(), "scatter_rows_: int64 ids, equal row width / dtype, one device");
+    TORCH_CHECK(idv.numel() <= s.size(0), "scatter_rows_: ", idv.numel(), " ids but the source has ", s.size(0), " rows");
     check_rc(rgn_scatter_rows(ptr(s), (const int64_t*)ptr(idv), d.data_ptr(), (int)idv.numel(), (int)(s.size(1) * s.element_size()),
                               stream_of(s)), "rgn_scatter_rows");
 }
@@ -177,10 +180,19 @@ Tensor cfg_combine(const Tensor& pos, const Tensor& neg, double scale, int64_t m
 }
 
 // ---- Region-Instruction KV cache -------------------------------------------------------------------------------------------
-rgn_qkv_epilogue epi(const Tensor& norm_q, const Tensor& norm_k, const Tensor& cos_q, const Tensor& sin_q, const Tensor& cos_k,
+// `x` = the activations of the problem this epilogue belongs to: its rows are sequence rows [row_base, row_base + M), every tensor of
+// the descriptor must live on its device and cover those rows (a C++ / AOT caller gets a TORCH_CHECK failure, never an
+// out-of-bounds device read or K / V scattered into arbitrary cache rows - advisor finding, round 4)
+rgn_qkv_epilogue epi(const Tensor& x, const Tensor& norm_q, const Tensor& norm_k, const Tensor& cos_q, const Tensor& sin_q, const Tensor& cos_k,
                      const Tensor& sin_k, const OptTensor& kv_rows, const Tensor& k_cache, const Tensor& vt_cache, int64_t heads,
                      int64_t row_base, double eps, bool fp16_roundtrip) {
-    const int64_t d = heads * 128, skv_pad = k_cache.size(0);
+    TORCH_CHECK(heads > 0 && k_cache.dim() == 2, "K slab [skv_pad, H*128]");
+    const int64_t d = heads * 128, skv_pad = k_cache.size(0), M = x.size(0);
+    const bool have_rows = kv_rows.has_value() && kv_rows->defined();
+    TORCH_CHECK(row_base >= 0, "row_base must be >= 0");
+    for (const Tensor* t : {&norm_q, &norm_k, &cos_q, &sin_q, &cos_k, &sin_k, &k_cache, &vt_cache})
+        TORCH_CHECK(t->device() == x.device(), "fused Q/K/V epilogue: every tensor must live on the activations' device ", x.device());
+    TORCH_CHECK(!have_rows || kv_rows->device() == x.device(), "kv_rows must live on the activations' device");
     TORCH_CHECK(k_cache.dim() == 2 && k_cache.size(1) == d && vt_cache.dim() == 2 && vt_cache.size(0) == d && vt_cache.size(1) == skv_pad &&
                     k_cache.is_contiguous() && vt_cache.is_contiguous(), "K slab [skv_pad, H*128] / V^T slab [H*128, skv_pad], contiguous");
     for (const Tensor* t : {&norm_q, &norm_k})
@@ -191,6 +203,16 @@ rgn_qkv_epilogue epi(const Tensor& norm_q, const Tensor& norm_k, const Tensor& c
     // the kernel reads 8-byte indices: an int32 tensor would be read past its end and scatter K / V to garbage cache rows
     TORCH_CHECK(!(kv_rows.has_value() && kv_rows->defined()) ||
                     (kv_rows->scalar_type() == at::kLong && kv_rows->dim() == 1 && kv_rows->is_contiguous()), "kv_rows: int64 [rows]");
+    // extents: the kernel reads cos_q / sin_q at sequence rows [row_base, row_base + M), kv_rows[row_base + m] for every row, and
+    // cos_k / sin_k at the CACHE row of each sequence row (identity rows: the same range; gathered rows: any row of the slab)
+    TORCH_CHECK(cos_q.size(0) >= row_base + M, "rotary table of the queries has ", cos_q.size(0), " rows, the problem needs ", row_base + M);
+    if (have_rows) {
+        TORCH_CHECK(kv_rows->numel() >= row_base + M, "kv_rows has ", kv_rows->numel(), " entries, the problem needs ", row_base + M);
+        TORCH_CHECK(cos_k.size(0) >= skv_pad || cos_k.size(0) >= row_base + M, "rotary table of the keys is shorter than the rows it is read at");
+    } else {
+        TORCH_CHECK(cos_k.size(0) >= row_base + M, "rotary table of the keys has ", cos_k.size(0), " rows, the problem needs ", row_base + M);
+        TORCH_CHECK(row_base + M <= skv_pad, "identity cache rows [", row_base, ", ", row_base + M, ") exceed the slab's ", skv_pad, " rows");
+    }
     rgn_qkv_epilogue e;
     e.wq = ptr(norm_q); e.wk = ptr(norm_k);
     e.cos_q = (const float*)ptr(cos_q); e.sin_q = (const float*)ptr(sin_q);
@@ -204,7 +226,13 @@ rgn_qkv_epilogue epi(const Tensor& norm_q, const Tensor& norm_k, const Tensor& c
 
 bool is_fp8(const Tensor& w) { return w.scalar_type() == at::kFloat8_e4m3fn; }
 
-void check_act(const Tensor& x, const Tensor& w, const Tensor& out, const OptTensor& wscale) {
+void check_act(const Tensor& x, const Tensor& w, const Tensor& out, const OptTensor& wscale, const OptTensor& bias = OptTensor()) {
+    TORCH_CHECK(w.device() == x.device() && out.device() == x.device(), "projection: activations, weights and output on one device");
+    if (bias.has_value() && bias->defined())
+        TORCH_CHECK(bias->scalar_type() == at::kBFloat16 && bias->dim() == 1 && bias->numel() == w.size(0) && bias->is_contiguous() &&
+                        bias->device() == x.device(), "projection: bias must be bf16 [N], contiguous, on the activations' device");
+    if (wscale.has_value() && wscale->defined())
+        TORCH_CHECK(wscale->is_contiguous() && wscale->device() == x.device(), "w_scale must be contiguous and on the activations' device");
     TORCH_CHECK(x.scalar_type() == at::kBFloat16 && out.scalar_type() == at::kBFloat16 && (w.scalar_type() == at::kBFloat16 || is_fp8(w)),
                 "projection: bf16 activations, bf16 or fp8 (e4m3fn) weights");
     TORCH_CHECK(x.dim() == 2 && w.dim() == 2 && out.dim() == 2 && x.stride(1) == 1 && w.stride(1) == 1 && out.stride(1) == 1 &&
@@ -218,8 +246,8 @@ void kv_partial_update_(const Tensor& x, const Tensor& w_kvq, const OptTensor& b
                         const OptTensor& kv_rows, Tensor k_cache, Tensor vt_cache, int64_t heads, int64_t row_base, double eps,
                         bool fp16_roundtrip, int64_t gelu_from_col, const OptTensor& w_scale) {
     RGN_DEVICE_GUARD(x);
-    check_act(x, w_kvq, q_out, w_scale);
-    rgn_qkv_epilogue e = epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip);
+    check_act(x, w_kvq, q_out, w_scale, b_kvq);
+    rgn_qkv_epilogue e = epi(x, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip);
     const int gelu = (int)(gelu_from_col < 0 ? 3 * heads * 128 : gelu_from_col);
     Tensor ws = gemm_ws(x);
     const int M = (int)x.size(0), N = (int)w_kvq.size(0), K = (int)x.size(1);
@@ -242,12 +270,12 @@ void kv_partial_update_pair_(const Tensor& x_img, const Tensor& w_img, const Opt
                              int64_t heads, int64_t txt_len, double eps, bool fp16_roundtrip, const OptTensor& w_scale_img,
                              const OptTensor& w_scale_txt) {
     RGN_DEVICE_GUARD(x_img);
-    check_act(x_img, w_img, out_img, w_scale_img);
-    check_act(x_txt, w_txt, out_txt, w_scale_txt);
+    check_act(x_img, w_img, out_img, w_scale_img, b_img);
+    check_act(x_txt, w_txt, out_txt, w_scale_txt, b_txt);
     TORCH_CHECK(w_img.sizes() == w_txt.sizes() && w_img.is_contiguous() && w_txt.is_contiguous() && is_fp8(w_img) == is_fp8(w_txt),
                 "pair: equal [N, K], contiguous weights of one format");
-    rgn_qkv_epilogue e0 = epi(norm_q_img, norm_k_img, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps, fp16_roundtrip);
-    rgn_qkv_epilogue e1 = epi(norm_q_txt, norm_k_txt, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, 0, eps, false);
+    rgn_qkv_epilogue e0 = epi(x_img, norm_q_img, norm_k_img, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps, fp16_roundtrip);
+    rgn_qkv_epilogue e1 = epi(x_txt, norm_q_txt, norm_k_txt, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, 0, eps, false);
     Tensor ws = gemm_ws(x_img);
     const int N = (int)w_img.size(0), K = (int)w_img.size(1);
     if (is_fp8(w_img))
@@ -282,10 +310,10 @@ void kv_partial_update_group_(at::TensorList x, at::TensorList w_kvq, const c10:
     std::vector<rgn_gemm_problem> ps;
     for (size_t i = 0; i < n; ++i) {
         OptTensor sc = w_scale.size() ? OptTensor(w_scale.get(i)) : OptTensor();
-        check_act(x[i], w_kvq[i], q_out[i], sc);
+        check_act(x[i], w_kvq[i], q_out[i], sc, OptTensor(b_kvq.get(i)));
         TORCH_CHECK(w_kvq[i].sizes() == w_kvq[0].sizes() && w_kvq[i].is_contiguous() && is_fp8(w_kvq[i]) == is_fp8(w_kvq[0]),
                     "group: equal [N, K], contiguous weights of one format");
-        es[i] = epi(norm_q[i], norm_k[i], cos_q[i], sin_q[i], cos_k[i], sin_k[i], kv_rows.get(i), k_cache[i], vt_cache[i], heads, row_base[i],
+        es[i] = epi(x[i], norm_q[i], norm_k[i], cos_q[i], sin_q[i], cos_k[i], sin_k[i], kv_rows.get(i), k_cache[i], vt_cache[i], heads, row_base[i],
                     eps, !fp16_roundtrip.empty() && fp16_roundtrip[i] != 0);
         if (x[i].size(0) == 0) continue;
         rgn_gemm_problem p;
@@ -316,6 +344,11 @@ void region_attention(const Tensor& q, const Tensor& k_cache, const Tensor& vt_c
 }
 
 }  // namespace
+
+// the header this binding was compiled against: regione_amd/torch_ops.py compares both with libregione_hip.so's rgn_version() /
+// rgn_abi_struct_bytes() before the first op runs (rgn_qkv_epilogue / rgn_gemm_problem travel by pointer)
+extern "C" int rgn_torch_binding_abi_version(void) { return RGN_ABI_VERSION; }
+extern "C" size_t rgn_torch_binding_struct_bytes(void) { return sizeof(rgn_qkv_epilogue) * 1000 + sizeof(rgn_gemm_problem); }
 
 // the schemas: identical to regione_amd/torch_ops.py (SCHEMAS there is the single source the tests compare both against)
 TORCH_LIBRARY(regione_mi, m) {

@@ -31,7 +31,6 @@ Engine layout (one image, B = 1):
 from __future__ import annotations
 
 import math
-import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -263,11 +262,15 @@ class FwdCtx:
 # ---------------------------------------------------------------------------------------------
 # [EXT] module tree
 # ---------------------------------------------------------------------------------------------
-# RGN_FUSE_QKV=0 keeps RMSNorm / RoPE / cache placement as the separate rgn_qk_norm_rope_store pass (A/B switch;
-# both paths produce bit-identical results, tests/test_gpu_kernels.py)
-FUSE_QKV = os.environ.get("RGN_FUSE_QKV", "1") != "0"
-# RGN_SKIP_UNREAD_ROWS=0: the last block and norm_out / proj_out run over every row like the reference (A/B switch)
-SKIP_UNREAD_ROWS = os.environ.get("RGN_SKIP_UNREAD_ROWS", "1") != "0"
+# Module-level engine options (plain attributes, no environment reads: tests flip them with monkeypatch.setattr).
+# FUSE_QKV: RMSNorm / RoPE / cache placement inside the projection GEMM's epilogue; False = the separate rgn_qk_norm_rope_store pass
+# (the path odd head counts and the row-skipping last block take anyway; both produce bit-identical results).
+FUSE_QKV = True
+# SKIP_UNREAD_ROWS: the last block and norm_out / proj_out compute only the rows the caller reads; False = every row, like the reference.
+SKIP_UNREAD_ROWS = True
+# ATTN_BRANCH_STREAMS: in a batched CFG pass the second branch's attention runs on a side stream (bench.py's per-launch timer
+# switches it off while it is installed: per-launch durations need launches that do not share the chip).
+ATTN_BRANCH_STREAMS = True
 
 
 class Attention:
@@ -440,11 +443,11 @@ class FluxAttnProcessor:
                 rows.append(kv_rows); kc.append(k_slab); vc.append(vt_slab); rb.append(row_base); rt.append(rtrip)
         TO.R.kv_partial_update_group_(xs, ws_, bs, outs, nq, nk, cq, sq, ck, sk, rows, kc, vc, H, rb, 1e-6, rt,
                                       3 * d if self.single else -1)
-        # the second branch's attention on a side stream (RGN_ATTN_BRANCH_STREAMS=0: A/B switch back to one stream): the same
+        # the second branch's attention on a side stream (ATTN_BRANCH_STREAMS above): the same
         # launches with the same arguments - bit-identical - but its first workgroups fill the CUs the first branch's stream-K
         # tail and merge pass leave idle (Qwen 1024^2 region step 65.0 -> 63.7 ms; full steps unchanged)
         side = None
-        if len(per) == 2 and os.environ.get("RGN_ATTN_BRANCH_STREAMS", "1") != "0":
+        if len(per) == 2 and ATTN_BRANCH_STREAMS:
             from .. import dist as D
             main = torch.cuda.current_stream()
             side = D.side_stream(main)

@@ -259,14 +259,33 @@ def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, g
 
 
 def qkv_epilogue(*, wq, wk, rope_q, rope_k, k_slab, vt_slab, H: int, k_col: int, v_col: int, q_col: int,
-                 kv_rows: Optional[torch.Tensor] = None, row_base: int = 0, eps: float = 1e-6, fp16_roundtrip: bool = False):
-    """Descriptor of the fused Q/K/V epilogue (struct rgn_qkv_epilogue); keeps its tensors alive."""
+                 kv_rows: Optional[torch.Tensor] = None, row_base: int = 0, eps: float = 1e-6, fp16_roundtrip: bool = False,
+                 rows: Optional[int] = None):
+    """Descriptor of the fused Q/K/V epilogue (struct rgn_qkv_epilogue); keeps its tensors alive.  `rows` = the row count M of
+    the problem the descriptor belongs to: with it the extents the kernel will read are checked here (the same checks as
+    csrc/torch_binding.cpp:epi) - rotary rows [row_base, row_base + M), kv_rows[row_base + m], identity cache rows inside the slab."""
     skv_pad = k_slab.shape[0]
     assert vt_slab.shape == (H * 128, skv_pad) and k_slab.shape[1] == H * 128 and k_slab.is_contiguous() and vt_slab.is_contiguous()
     for t in (rope_q[0], rope_q[1], rope_k[0], rope_k[1]):
         assert t.dtype == torch.float32 and t.shape[1] == 128 and t.is_contiguous()
+    assert rope_q[0].shape == rope_q[1].shape and rope_k[0].shape == rope_k[1].shape, "cos / sin of one rotary table differ in shape"
+    for w in (wq, wk):
+        assert w.dtype == torch.bfloat16 and w.numel() == 128 and w.is_contiguous(), "per-head RMSNorm weights: bf16 [128]"
     # the kernel reads 8-byte indices: an int32 tensor would be read past its end and scatter K / V to garbage cache rows
     assert kv_rows is None or (kv_rows.dtype == torch.int64 and kv_rows.dim() == 1 and kv_rows.is_contiguous())
+    dev = k_slab.device
+    for t in (wq, wk, rope_q[0], rope_q[1], rope_k[0], rope_k[1], vt_slab) + ((kv_rows,) if kv_rows is not None else ()):
+        if t.device != dev:
+            raise _lib.RegionEHipError(f"fused Q/K/V epilogue: tensors on {t.device} and {dev} (one device per problem)")
+    if rows is not None:
+        need = row_base + int(rows)
+        if row_base < 0 or rope_q[0].shape[0] < need:
+            raise _lib.RegionEHipError(f"rotary table of the queries has {rope_q[0].shape[0]} rows, the problem needs {need}")
+        if kv_rows is not None:
+            if kv_rows.numel() < need:
+                raise _lib.RegionEHipError(f"kv_rows has {kv_rows.numel()} entries, the problem needs {need}")
+        elif rope_k[0].shape[0] < need or need > skv_pad:
+            raise _lib.RegionEHipError(f"identity cache rows [{row_base}, {need}) exceed the key rotary table / the slab's {skv_pad} rows")
     e = _lib.QkvEpilogue(_p(wq), _p(wk), _p(rope_q[0]), _p(rope_q[1]), _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows),
                          _p(k_slab), _p(vt_slab), row_base, skv_pad, k_col, v_col, q_col, H, eps, int(fp16_roundtrip))
     e._keep = (wq, wk, rope_q, rope_k, kv_rows, k_slab, vt_slab)

@@ -55,8 +55,17 @@ if _mode in ("", "1"):
 if _mode == "cpp":
     if not _os.path.exists(CPP_LIB):
         raise ops._lib.RegionEHipError(f"RGN_TORCH_OPS=cpp but {CPP_LIB} is not built (python -m regione_amd.build)")
-    ops._lib.lib()                                  # libregione_hip.so first (the binding links against it by $ORIGIN rpath)
+    _h = ops._lib.lib()                             # libregione_hip.so first (the binding links against it by $ORIGIN rpath)
     torch.ops.load_library(CPP_LIB)                 # TORCH_LIBRARY(regione_mi) + CUDA kernels: defined by the library itself
+    # a binding compiled against another regione_hip.h than the HIP library next to it would misread the structs it passes by
+    # pointer (advisor finding, round 4): both carry the header's ABI stamp - compare before any op can run
+    import ctypes as _C
+    _b = _C.CDLL(CPP_LIB)
+    _b.rgn_torch_binding_struct_bytes.restype = _C.c_size_t
+    if (_b.rgn_torch_binding_abi_version(), _b.rgn_torch_binding_struct_bytes()) != (_h.rgn_version(), _h.rgn_abi_struct_bytes()):
+        raise ops._lib.RegionEHipError(
+            f"{CPP_LIB} was built against ABI {_b.rgn_torch_binding_abi_version()} / struct bytes {_b.rgn_torch_binding_struct_bytes()}, "
+            f"libregione_hip.so is {_h.rgn_version()} / {_h.rgn_abi_struct_bytes()}: rebuild (python -m regione_amd.build --force)")
     _lib = None
 else:
     _lib = torch.library.Library(NS, "FRAGMENT")   # (the dispatcher omits trailing arguments that equal their schema default:
@@ -120,11 +129,11 @@ _define("cfg_combine", "(Tensor pos, Tensor neg, float scale, int mode=0, float 
 
 
 # ---- Region-Instruction KV cache ------------------------------------------------------------------
-def _epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip):
+def _epi(x, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip):
     d = heads * 128
     return ops.qkv_epilogue(wq=norm_q, wk=norm_k, rope_q=(cos_q, sin_q), rope_k=(cos_k, sin_k), k_slab=k_cache,
                             vt_slab=vt_cache, H=heads, k_col=0, v_col=d, q_col=2 * d, kv_rows=kv_rows, row_base=row_base,
-                            eps=eps, fp16_roundtrip=fp16_roundtrip)
+                            eps=eps, fp16_roundtrip=fp16_roundtrip, rows=x.shape[0])
 
 
 def _scaled(w, w_scale):
@@ -137,7 +146,7 @@ def _scaled(w, w_scale):
 def _kv_update(x, w_kvq, b_kvq, q_out, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base=0,
                eps=1e-6, fp16_roundtrip=False, gelu_from_col=-1, w_scale=None):
     w_kvq = _scaled(w_kvq, w_scale)
-    epi = _epi(norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip)
+    epi = _epi(x, norm_q, norm_k, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, row_base, eps, fp16_roundtrip)
     ops.gemm_qkv(x, w_kvq, b_kvq, q_out, epi, gelu_from_col=3 * heads * 128 if gelu_from_col < 0 else gelu_from_col)
 
 
@@ -151,8 +160,8 @@ def _kv_update_pair(x_img, w_img, b_img, out_img, norm_q_img, norm_k_img, x_txt,
                     cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps=1e-6, fp16_roundtrip=False,
                     w_scale_img=None, w_scale_txt=None):
     w_img, w_txt = _scaled(w_img, w_scale_img), _scaled(w_txt, w_scale_txt)
-    e_img = _epi(norm_q_img, norm_k_img, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps, fp16_roundtrip)
-    e_txt = _epi(norm_q_txt, norm_k_txt, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, 0, eps, False)
+    e_img = _epi(x_img, norm_q_img, norm_k_img, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, txt_len, eps, fp16_roundtrip)
+    e_txt = _epi(x_txt, norm_q_txt, norm_k_txt, cos_q, sin_q, cos_k, sin_k, kv_rows, k_cache, vt_cache, heads, 0, eps, False)
     ops.gemm_qkv_pair(x_img, w_img, b_img, out_img, e_img, x_txt, w_txt, b_txt, out_txt, e_txt)
 
 
@@ -172,7 +181,7 @@ def _kv_update_group(x, w, w_scale, b, out, norm_q, norm_k, cos_q, sin_q, cos_k,
     if len(w_scale):
         w = [_scaled(wi, si) for wi, si in zip(w, w_scale)]
     probs = [ops.Problem(x[i], w[i], b[i], out[i],
-                         epi=_epi(norm_q[i], norm_k[i], cos_q[i], sin_q[i], cos_k[i], sin_k[i], kv_rows[i], k_cache[i], vt_cache[i],
+                         epi=_epi(x[i], norm_q[i], norm_k[i], cos_q[i], sin_q[i], cos_k[i], sin_k[i], kv_rows[i], k_cache[i], vt_cache[i],
                                   heads, int(row_base[i]), eps, bool(rt[i]))) for i in range(len(x))]
     ops.gemm_group(probs, epilogue=3, gelu_from_col=0 if gelu_from_col < 0 else gelu_from_col)
 

@@ -23,6 +23,8 @@ except Exception as _e:          # noqa: BLE001 - reported, not fatal: test_capi
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_long: MI355X parity cases at full dimensions that cost 35-50 s of CPU oracle each; NOT part of "
+                                       "`-m gpu` (kept under 300 s) - run with -m gpu_long, log committed under profiles/")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -31,8 +33,20 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="needs a HIP GPU (torch.cuda.is_available() is False)")
     for item in items:
-        if "gpu" in item.keywords:
+        if "gpu" in item.keywords or "gpu_long" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _reset_plan_overrides():
+    """Launch-plan knobs forced by a test (tests/plan_helpers.py, rgn_plan_override) never leak into the next one."""
+    yield
+    try:
+        from regione_amd import _lib
+        if _lib._lib is not None:
+            _lib._lib.rgn_plan_override(None, 0)
+    except Exception:          # noqa: BLE001 - a missing library is reported by the tests that need it
+        pass
 
 
 def load_golden(name):

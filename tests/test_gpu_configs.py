@@ -12,7 +12,7 @@ import torch
 from oracle import regione_oracle as O
 from regione_amd import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = []          # per test: `gpu`, or `gpu_long` for the bf16 twin of configs[4] (the config itself is fp8 weights)
 
 
 def _ids_partition_ok(M, h, w, box):
@@ -23,6 +23,7 @@ def _ids_partition_ok(M, h, w, box):
     return e
 
 
+@pytest.mark.gpu
 def test_config3_flux_1024_true_cfg6_full_size(golden):
     """Two forwards per computed step.  Default: one K/V cache per branch tag (the fix Qwen / Step1X-v1p2 apply);
     strict_reference=True: ONE cache shared by both branches like the reference (quirk A-4, inplace.py:700-702)."""
@@ -67,7 +68,7 @@ def test_config3_flux_1024_true_cfg6_full_size(golden):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+@pytest.mark.parametrize("weights", [pytest.param("bf16", marks=pytest.mark.gpu_long), pytest.param("fp8", marks=pytest.mark.gpu)])
 def test_config4_step1x_v1p2_2048_50_steps(golden, weights):
     """L = L_c = 16384 (S = 33280 / 33152 rows per branch), 50 denoising steps, tagged sequential CFG 6.0 with text
     lengths 512 / 384, one K/V cache per branch (2 x 23 GB).  `weights="fp8"`: the trunk's GEMM weights are OCP e4m3

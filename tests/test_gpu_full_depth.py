@@ -24,10 +24,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-pytestmark = pytest.mark.gpu
-
-
-@pytest.mark.parametrize("family", ["flux", "qwen"])
+# the Qwen full-width case (36 s of CPU oracle) runs under -m gpu_long; `-m gpu` keeps FLUX (the headline family) and all three loops
+@pytest.mark.parametrize("family", [pytest.param("flux", marks=pytest.mark.gpu), pytest.param("qwen", marks=pytest.mark.gpu_long)])
 def test_full_depth_full_width_full_store_then_region_step_vs_oracle(family):
     import parity_full_depth as P
     r = P.full_width(family, truth=False)
@@ -38,14 +36,22 @@ def test_full_depth_full_width_full_store_then_region_step_vs_oracle(family):
     assert r["untouched_rows_bit_identical"]
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("family", ["flux", "qwen", "step1x_v1p2"])
 def test_full_depth_trunk_28_steps_vs_oracle_denoise(family):
+    """FLUX and Step1X-Edit v1p2: the north star's 40 dB, hard.  Qwen is the ONE explicit exception (advisor, round 4): 60 blocks and
+    a norm-preserving CFG combine `neg + 4 (pos - neg)` put the oracle's own re-ordered run 39.9 dB from itself, so the bar for
+    that family is "no further from the oracle than 2 dB below the oracle's own spread" AND >= 38 dB absolute; round 5 attributes
+    the gap per branch (profiles/r05_parity_qwen_branches.json: both branch velocities >= 40 dB, the combine amplifies)."""
     import parity_full_depth as P
-    r = P.narrow_loop(family)
+    r = P.narrow_loop(family, alt=(family == "qwen"))
     assert r["blocks"] == (60 if family == "qwen" else 57)
     assert r["hip_plan"] == r["oracle_plan"] and "R" in r["hip_plan"] and "C" in r["hip_plan"]
     assert r["ids_bit_exact"] and 0 < r["hip_K_e"] < 256
-    assert r["oracle_reordered_ids_equal"]
-    spread = r["psnr_oracle_reordered_vs_oracle_db"]
-    assert r["psnr_final_db"] >= 40.0 or r["psnr_final_db"] >= spread - 2.0, (r["psnr_final_db"], spread)
+    if family == "qwen":
+        assert r["oracle_reordered_ids_equal"]
+        spread = r["psnr_oracle_reordered_vs_oracle_db"]
+        assert r["psnr_final_db"] >= 38.0 and r["psnr_final_db"] >= spread - 2.0, (r["psnr_final_db"], spread)
+    else:
+        assert r["psnr_final_db"] >= 40.0, r["psnr_final_db"]
     assert torch.isfinite(torch.tensor(r["rel_final"]))

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import regione_oracle as O
+import plan_helpers as P
 
 pytestmark = pytest.mark.gpu
 
@@ -22,14 +23,14 @@ def rel_err(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["128", "256c", "256"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (300, 256, 192), (1, 128, 64), (1000, 64, 3072),
                                    (777, 200, 128), (8704, 3072, 3072)])
-def test_gemm_bias(M, N, K, variant, monkeypatch):
+def test_gemm_bias(M, N, K, variant):
     from regione_amd import ops
-    # 1 = 128x128 tiles, 2 = 256x256 tiles (8 waves, hipcc-scheduled loop), 3 = 256x256 tiles with the hand-scheduled
+    # 128 = 128x128 tiles, 256c = 256x256 tiles (8 waves, hipcc-scheduled loop), 256 = 256x256 tiles with the hand-scheduled
     # 4-wave K loop wherever it applies (K >= 128)
-    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    P.geometry(variant)
     g = torch.Generator().manual_seed(M * 7 + N)
     # asymmetric operands so a transposed C-write cannot pass (guide rule 16)
     A = bf(torch.randn(M, K, generator=g))
@@ -84,10 +85,10 @@ def test_gemm_strided_views_scatter_and_epilogues():
     assert rel_err(cache.cpu()[idx], ref[idx]) < 3e-3
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
-def test_gemm_pair_two_problems_one_launch(variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["128", "256c", "256"])
+def test_gemm_pair_two_problems_one_launch(variant):
     from regione_amd import ops
-    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    P.geometry(variant)
     g = torch.Generator().manual_seed(9)
     N, K, M0, M1 = 384, 256, 700, 90
     A0, A1 = bf(torch.randn(M0, K, generator=g)).cuda(), bf(torch.randn(M1, K, generator=g)).cuda()
@@ -216,7 +217,7 @@ def test_attention_shapes(Sq, Skv, H):
 
 @pytest.mark.parametrize("Sq,Skv,H", [(717, 8704, 24), (1024, 8704, 24), (1137, 8576, 24), (2537, 8704, 24), (1408, 1600, 24),
                                       (4608, 33280, 24)])
-def test_attention_stream_k_remainder(Sq, Skv, H, monkeypatch):
+def test_attention_stream_k_remainder(Sq, Skv, H):
     """Region-step query sets (Sq = T + K_e) leave fewer items than CUs: the (item, KV tile) steps are dealt out in equal
     contiguous runs (stream-K), a run may cross one item boundary, attention_combine_sk_kernel merges the partials.  Must agree
     with the unsplit schedule, with the equal-split schedule and with an fp32 reference (ragged last query block, a spiky key
@@ -237,10 +238,9 @@ def test_attention_stream_k_remainder(Sq, Skv, H, monkeypatch):
     vt = torch.zeros(D, pad, dtype=torch.bfloat16, device="cuda")
     vt[:, pos] = v.T
     outs = {}
-    for name, env in (("stream_k", {"RGN_ATTN_STREAMK": "2"}), ("auto", {}), ("equal_split", {"RGN_ATTN_STREAMK": "0"}), ("unsplit", {"RGN_ATTN_VARIANT": "8n"})):
-        with monkeypatch.context() as mp:
-            for key, val in env.items():
-                mp.setenv(key, val)                      # both switches are read per call
+    for name, knobs in (("stream_k", dict(attn_streamk=1)), ("auto", {}), ("equal_split", dict(attn_streamk=0)),
+                        ("unsplit", dict(attn_waves=8, attn_split=0))):
+        with ops._lib.plan_override(**knobs):
             o = torch.empty_like(q)
             ops.attention(q, ks, vt, o, Skv, H)
             torch.cuda.synchronize()
@@ -274,13 +274,9 @@ def test_gemm_round_aware_split_k_path():
     plan = _lib.lib().rgn_gemm_last_plan()
     assert (plan & 0x400) and (plan & 0xff) > 1, f"the remainder was not cut along K (plan {plan:#x})"
     assert rel_err(out.cpu(), lin.cpu()) < 3e-3
-    import os
-    os.environ["RGN_GEMM_SPLIT"] = "0"
-    try:
+    with _lib.plan_override(gemm_pieces=1):
         out2 = torch.empty_like(out)
         ops.gemm(A, W, b, out2)
-    finally:
-        del os.environ["RGN_GEMM_SPLIT"]
     # split and unsplit schedules agree to fp32 summation order (<= 1 bf16 ulp on a few elements)
     assert float((out != out2).float().mean()) < 0.02
     assert float((out.float() - out2.float()).abs().max()) <= 2 ** -7 * float(out2.float().abs().max())
@@ -294,7 +290,6 @@ def test_attention_full_size_round_aware_vs_unsplit():
     """Sq = Skv = 8704, H = 24 (FLUX full step): 816 items = 3 full rounds + 48 remainder items that are cut
     along KV and merged; must agree with the unsplit schedule and with an fp32 reference on sampled rows."""
     from regione_amd import ops
-    import os
     g = torch.Generator().manual_seed(33)
     S, H = 8704, 24
     D = H * 128
@@ -307,12 +302,9 @@ def test_attention_full_size_round_aware_vs_unsplit():
     vt[:, pos] = v.T
     out = torch.empty_like(q)
     ops.attention(q, k, vt, out, S, H)
-    os.environ["RGN_ATTN_VARIANT"] = "8n"
-    try:
+    with ops._lib.plan_override(attn_waves=8, attn_split=0):
         out2 = torch.empty_like(q)
         ops.attention(q, k, vt, out2, S, H)
-    finally:
-        del os.environ["RGN_ATTN_VARIANT"]
     assert rel_err(out.cpu(), out2.cpu()) < 2e-3
     rows = torch.randperm(S, generator=g)[:256].sort().values.cuda()
     qq = q[rows].float().view(-1, H, 128).transpose(0, 1)
@@ -341,15 +333,15 @@ def _qkv_case(M, H, K, mlp, gen, kv_rows=None, skv=None, row_base=0):
     return A, W, b, wq, wk, (cos, sin), D, N, skv
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["128", "256c", "256"])
 @pytest.mark.parametrize("M,H,K,mlp,gather,row_base", [(600, 2, 256, 1024, False, 0), (333, 2, 256, 0, True, 0),
                                                        (512, 4, 512, 2048, False, 16), (200, 2, 256, 0, True, 24)])
-def test_gemm_qkv_fused_epilogue_bit_identical_to_separate_kernels(M, H, K, mlp, gather, row_base, variant, monkeypatch):
+def test_gemm_qkv_fused_epilogue_bit_identical_to_separate_kernels(M, H, K, mlp, gather, row_base, variant):
     """rgn_gemm_bf16_qkv == rgn_gemm_bf16 followed by rgn_qk_norm_rope_store, bit for bit: Q (in place), the
     GELU(mlp) columns, the K slab and the V^T slab - identity rows, gathered cache rows (region step) and a
     problem that starts at a joint-sequence offset that is / is not a multiple of 16."""
     from regione_amd import ops
-    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    P.geometry(variant)
     gen = torch.Generator().manual_seed(M + H)
     skv = row_base + (M if not gather else 3 * M)
     A, W, b, wq, wk, rope, D, N, skv = _qkv_case(M, H, K, mlp, gen, skv=skv, row_base=row_base)
@@ -446,7 +438,7 @@ def test_gemm_qkv_fp16_roundtrip_option():
 @pytest.mark.parametrize("nsplit", [2, 3, 5])
 @pytest.mark.parametrize("shape,epi", [((1536, 3072, 15360), "gate"), ((8704, 3072, 15360), "gate"), ((708, 3072, 12288), "bias"),
                                        (((1024, 512), 3072, 12288), "gate"), (((196, 512), 12288, 3072), "gelu")])
-def test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled(shape, epi, nsplit, monkeypatch):
+def test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled(shape, epi, nsplit):
     """Remainder tiles are cut along K: every piece runs the hand-scheduled K loop over its K range and dumps fp32 fragments,
     a reduce launch of the same geometry sums them in index order (batched loads into the AGPR accumulators) and runs the
     epilogue.  Same piece count -> bit-identical to the 8-wave partial + reduce launches, launch after launch, and within
@@ -473,86 +465,26 @@ def test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled(
             ops.gemm(As[0], Ws[0], b, outs[0], epilogue=E, **kw)
         torch.cuda.synchronize()
         return torch.cat(outs)
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
-    monkeypatch.setenv("RGN_GEMM_NSPLIT", str(nsplit))
+    P.geometry("256")
+    P.force(gemm_pieces=nsplit)
     fix = [run() for _ in range(3)]
     assert torch.equal(fix[0], fix[1]) and torch.equal(fix[0], fix[2])
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "2")                   # 8-wave geometry for the pieces and the reduce pass
+    P.geometry("256c")                                            # 8-wave geometry for the pieces and the reduce pass
     red = run()
     assert torch.equal(fix[0], red), float((fix[0].float() - red.float()).abs().max())
-    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")
+    P.force(gemm_pieces=1)
     whole = run()
     assert rel_err(fix[0].cpu(), whole.cpu()) < 2e-3
 
 
-@pytest.mark.parametrize("nsplit", [2, 3, 6])
-@pytest.mark.parametrize("case", ["gate", "bias_ragged", "gelu", "fp8_gate", "group4_gate", "scatter"])
-def test_gemm_split_k_fine_reduce_bit_identical_to_tile_reduce(case, nsplit, monkeypatch):
-    """Round 4: the reduce pass of a split-K remainder as 8 workgroups per tile with the epilogue in registers
-    (gemm_reduce4w_kernel) against the one-workgroup-per-tile pass (RGN_GEMM_FINE_REDUCE=0): same summation order, same epilogue
-    expressions -> torch.equal, for every epilogue it serves, ragged M / N edges, fp8 weights (channel scale on the fp32 sum),
-    a four-problem group with per-problem gates and the row-scatter form."""
-    from regione_amd import ops
-    g = torch.Generator().manual_seed(len(case) * 7 + nsplit)
-    K = 6144
-    N = {"bias_ragged": 712, "gelu": 1024}.get(case, 3072)
-    Ms = [1024, 1000, 512, 300] if case == "group4_gate" else [777]
-    As = [bf(torch.randn(m, K, generator=g)).cuda() for m in Ms]
-    W0 = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
-    W1 = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
-    if case == "fp8_gate":
-        W0 = ops.quantize_w8(W0)
-    Ws = [W0, W0, W1, W1][:len(Ms)]
-    b = bf(torch.randn(N, generator=g)).cuda()
-    gates = [bf(torch.randn(N, generator=g)).cuda() for _ in Ms]
-    xs = [bf(torch.randn(m, N, generator=g)).cuda() for m in Ms]
-    rows = torch.randperm(1500, generator=g)[:Ms[0]].cuda() if case == "scatter" else None
-    big = bf(torch.randn(1500, N, generator=g)).cuda() if case == "scatter" else None
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
-    monkeypatch.setenv("RGN_GEMM_NSPLIT", str(nsplit))
-
-    def run():
-        outs = [x.clone() for x in xs]
-        if case == "scatter":
-            o = big.clone()
-            ops.gemm(As[0], Ws[0], b, o, out_rows=rows)
-            outs = [o]
-        elif case.endswith("gate"):
-            ops.gemm_group([ops.Problem(a, w, b, o, gate=gt, resid=o) for a, w, o, gt in zip(As, Ws, outs, gates)], epilogue=ops.EPI_GATE_RESID)
-        elif case == "gelu":
-            ops.gemm(As[0], Ws[0], b, outs[0], epilogue=ops.EPI_GELU, gelu_from_col=512)
-        else:
-            ops.gemm(As[0], Ws[0], b, outs[0])
-        torch.cuda.synchronize()
-        assert ops._lib.lib().rgn_gemm_last_plan() & 255 == nsplit
-        return torch.cat(outs)
-    monkeypatch.setenv("RGN_GEMM_FINE_REDUCE", "1")
-    fine = run()
-    monkeypatch.setenv("RGN_GEMM_FINE_REDUCE", "0")
-    tile = run()
-    assert torch.equal(fine, tile), float((fine.float() - tile.float()).abs().max())
-    assert torch.isfinite(fine.float()).all()
-
-
-@pytest.mark.parametrize("asmv", ["0", "1"])
 @pytest.mark.parametrize("M,N,K,epi", [(8704, 3072, 3072, "bias"), (1536, 21504, 3072, "gelu"), (700, 3072, 15360, "gate"),
                                        (513, 520, 128, "bias"), (8192, 512, 192, "gelu"), (300, 704, 256, "gate"),
                                        (2000, 1000, 320, "bias")])
-def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, epi, asmv, monkeypatch):
-    """The 4-wave asm K loop (variant 3) accumulates every output element over k in the same MFMA order as the 8-wave
-    kernel (variant 2): results must be bit-identical, for every epilogue, ragged edges included.  asmv 0 = two 64 KiB
-    stages, 1 = A ring of two / W ring of three 32 KiB slots (K >= 256; shorter K falls back to asmv 0)."""
+def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, epi):
+    """The 4-wave asm K loop ("256": A ring of two / W ring of three 32 KiB slots for K >= 256, the two-stage loop for K = 128 /
+    192) accumulates every output element over k in the same MFMA order as the 8-wave compiler-scheduled kernel ("256c", the
+    fallback geometry): results must be bit-identical, for every epilogue, ragged edges included."""
     from regione_amd import ops
-    import subprocess, sys, os
-    if asmv == "1":
-        # RGN_GEMM_ASMV is read once per process: run this case in a child
-        env = dict(os.environ, RGN_GEMM_ASMV="1", PYTEST_ASMV_CHILD="1")
-        if os.environ.get("PYTEST_ASMV_CHILD") != "1":
-            r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", __file__, "-k",
-                                f"test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled and {M}-{N}-{K}-{epi}-1"],
-                               env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
-            assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-            return
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).cuda()
     W = bf(torch.randn(N, K, generator=g) * 0.05).cuda()
@@ -561,9 +493,9 @@ def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, e
     outs = []
     # whole-K tiles only: the two geometries' launch planners may cut a remainder into different numbers of K pieces
     # (split remainders at EQUAL piece counts: test_gemm_split_k_hand_scheduled_pieces_bit_identical_to_compiler_scheduled)
-    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")
-    for variant in ("2", "3"):
-        monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    P.force(gemm_pieces=1)
+    for variant in ("256c", "256"):
+        P.geometry(variant)
         if epi == "gate":
             o = x.clone()
             ops.gemm(A, W, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
@@ -578,15 +510,15 @@ def test_gemm_hand_scheduled_loop_bit_identical_to_compiler_scheduled(M, N, K, e
         assert rel_err(outs[1].cpu(), ref.cpu()) < 3e-3
 
 
-@pytest.mark.parametrize("M,N,K,epi,variant", [(8704, 3072, 3072, "bias", "2"), (1536, 21504, 3072, "gelu", "2"), (700, 3072, 15360, "gate", "2"),
-                                               (513, 520, 128, "bias", "1"), (300, 704, 256, "gate", "1"), (2000, 1000, 320, "bias", "2")])
-def test_gemm_fp8_weights_per_channel_scale(M, N, K, epi, variant, monkeypatch):
+@pytest.mark.parametrize("M,N,K,epi,variant", [(8704, 3072, 3072, "bias", "256c"), (1536, 21504, 3072, "gelu", "256c"), (700, 3072, 15360, "gate", "256c"),
+                                               (513, 520, 128, "bias", "128"), (300, 704, 256, "gate", "128"), (2000, 1000, 320, "bias", "256c")])
+def test_gemm_fp8_weights_per_channel_scale(M, N, K, epi, variant):
     """rgn_gemm_w8: W stored as OCP e4m3fn + one fp32 scale per output channel.  Reference = the same GEMM on the
     DEQUANTISED weights in fp32 (the conversion fp8 -> bf16 in the kernel is exact; the scale multiplies the fp32
     accumulator): the result must agree to bf16 output rounding - tolerance 2^-8 relative + accumulation noise, like the
     bf16 kernel against its fp32 reference."""
     from regione_amd import ops
-    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    P.geometry(variant)
     g = torch.Generator().manual_seed(M + N + K + 1)
     A = bf(torch.randn(M, K, generator=g)).cuda()
     W = bf(torch.randn(N, K, generator=g) * 0.05 * (1 + torch.arange(N)[:, None] % 7)).cuda()     # rows of different magnitude
@@ -659,72 +591,15 @@ def test_gemm_fp8_weights_fused_qkv_epilogue_and_pair():
     assert torch.equal(o0, s0) and torch.equal(o1, s1)
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(4608, 3072, 3072, "gate"), (8704, 21504, 3072, "gelu"), (2048, 704, 15360, "bias")])
-def test_gemm_fp8_weights_widened_once_bit_identical_to_fp8_tiles(M, N, K, epi, monkeypatch):
-    """Large-M problems on fp8 weights widen W (exact e4m3 -> bf16) once per call into the workspace tail and run the
-    hand-scheduled bf16 loop with the per-channel scale still on the fp32 accumulator: bit-identical to the kernel that
-    converts fp8 tiles in registers (RGN_W8_WIDEN_MIN_M=0)."""
-    from regione_amd import ops
-    g = torch.Generator().manual_seed(M + N)
-    A = bf(torch.randn(M, K, generator=g)).cuda()
-    Wq = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
-    b = bf(torch.randn(N, generator=g)).cuda()
-    gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
-    outs = []
-    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")          # whole-K tiles: the two paths' planners may cut remainders differently
-    for min_m in ("0", "1"):
-        monkeypatch.setenv("RGN_W8_WIDEN_MIN_M", min_m)
-        if epi == "gate":
-            o = x.clone()
-            ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
-        else:
-            o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-            ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GELU if epi == "gelu" else ops.EPI_BIAS, gelu_from_col=N // 2 // 8 * 8)
-        torch.cuda.synchronize()
-        outs.append(o)
-    assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
-    assert torch.isfinite(outs[0].float()).all()
-
-
-def test_gemm_group_shared_fp8_weights_widened_once_per_matrix(monkeypatch):
-    """The widen-once A/B path (RGN_W8_WIDEN_MIN_M=1) on a four-problem group whose CFG branches share the stream's fp8 weight
-    matrix: the de-duplication branch of `widen_w8` (second user of a matrix points at the first one's widened copy) gives
-    the launch the fp8-tile path gives, bit for bit (advisor finding, round 3: the branch had no test)."""
-    from regione_amd import ops
-    g = torch.Generator().manual_seed(23)
-    N, K = 3072, 3072
-    Ms = [1536, 1408, 512, 384]
-    As = [bf(torch.randn(m, K, generator=g)).cuda() for m in Ms]
-    W0 = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
-    W1 = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
-    b0, b1 = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(N, generator=g)).cuda()
-    Ws, bs = [W0, W0, W1, W1], [b0, b0, b1, b1]
-    gates = [bf(torch.randn(N, generator=g)).cuda() for _ in Ms]
-    res = [bf(torch.randn(m, N, generator=g)).cuda() for m in Ms]
-    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")          # whole-K tiles: the two paths' planners may cut remainders differently
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
-    outs = []
-    for widen in ("0", "1"):
-        monkeypatch.setenv("RGN_W8_WIDEN_MIN_M", widen)
-        xs = [r.clone() for r in res]
-        ops.gemm_group([ops.Problem(a, w, b, x, gate=gt, resid=x) for a, w, b, x, gt in zip(As, Ws, bs, xs, gates)],
-                       epilogue=ops.EPI_GATE_RESID)
-        torch.cuda.synchronize()
-        outs.append(xs)
-    for a, b in zip(*outs):
-        assert torch.equal(a, b) and torch.isfinite(a.float()).all()
-    assert not torch.equal(outs[0][0], res[0])
-
-
 # ---------------------------------------------------------------------------------------------------------------------
 # round 3: up to four problems per launch (text / image stream x cond / uncond CFG branch), segmented LN-modulate
 # ---------------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
-def test_gemm_group_four_problems_shared_weights_identical_to_separate_launches(variant, monkeypatch):
+@pytest.mark.parametrize("variant", ["128", "256c", "256"])
+def test_gemm_group_four_problems_shared_weights_identical_to_separate_launches(variant):
     """[image_cond, image_uncond] share W0, [text_cond, text_uncond] share W1; per-problem gate / residual.  Small shapes
     take no split-K path, so every output element sees the same accumulation order as in a launch of its own."""
     from regione_amd import ops
-    monkeypatch.setenv("RGN_GEMM_VARIANT", variant)
+    P.geometry(variant)
     g = torch.Generator().manual_seed(19)
     N, K = 384, 256
     Ms = [700, 650, 90, 77]
@@ -759,14 +634,14 @@ def test_gemm_group_four_problems_shared_weights_identical_to_separate_launches(
 
 
 @pytest.mark.parametrize("split", ["0", None])
-def test_gemm_group_region_step_shapes_of_two_cfg_branches(split, monkeypatch):
+def test_gemm_group_region_step_shapes_of_two_cfg_branches(split):
     """The region-step shapes of a batched CFG forward at FLUX / Qwen dimensions: image rows 1024 + 1024, text rows
     512 + 384, K = 3072 -> N = 12288 (ff1) and K = 12288 -> N = 3072 (ff2, gated residual).  Without the split-K schedule
-    (RGN_GEMM_SPLIT=0) the group is bit-identical to per-branch pair launches; with it the piece count may differ between
+    (gemm_pieces = 1) the group is bit-identical to per-branch pair launches; with it the piece count may differ between
     the two launch shapes (fp32 summation order), so the comparison is against a float64 reference."""
     from regione_amd import ops
     if split is not None:
-        monkeypatch.setenv("RGN_GEMM_SPLIT", split)
+        P.force(gemm_pieces=1)
     g = torch.Generator().manual_seed(23)
     d, ff = 3072, 12288
     Mi, Ts = 1024, (512, 384)
@@ -869,23 +744,21 @@ def test_ln_modulate_four_segments():
 
 @pytest.mark.parametrize("M,N,K,epi", [(4608, 3072, 3072, "gate"), (8704, 21504, 3072, "gelu"), (2048, 704, 15360, "bias"),
                                        (1536, 3072, 15360, "gate"), (600, 520, 256, "bias"), (9216, 9216, 3072, "bias")])
-def test_gemm_fp8_weights_in_the_hand_scheduled_loop_bit_identical_to_fp8_tile_and_widened_paths(M, N, K, epi, monkeypatch):
+def test_gemm_fp8_weights_in_the_hand_scheduled_loop_bit_identical_to_the_fp8_tile_kernel(M, N, K, epi):
     """Round 3: fp8 (e4m3fn) weight tiles INSIDE the hand-scheduled 4-wave K loop (W ring of three 16 KiB byte slots,
     ds_read_b64 + in-register v_cvt_scalef32_pk_bf16_fp8 ahead of the MFMAs; the default for 256 x 256 tiles) against the
-    compiler-scheduled fp8-tile kernel (RGN_W8_ASM=0) and the widen-once path of round 2 (RGN_W8_WIDEN_MIN_M=1): the
-    conversion is exact and the MFMA order per output element is the same, so all three agree bit for bit."""
+    compiler-scheduled fp8-tile kernel (gemm_asm = 0: the fallback for K < 256 / operands >= 4 GiB): the conversion is exact and the
+    MFMA order per output element is the same, so both agree bit for bit."""
     from regione_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     A = bf(torch.randn(M, K, generator=g)).cuda()
     Wq = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
     b = bf(torch.randn(N, generator=g)).cuda()
     gate, x = bf(torch.randn(N, generator=g)).cuda(), bf(torch.randn(M, N, generator=g)).cuda()
-    monkeypatch.setenv("RGN_GEMM_SPLIT", "0")          # whole-K tiles: the paths' planners may cut remainders differently
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")        # 256 x 256 tiles on every path
+    P.force(gemm_pieces=1, gemm_geometry=256)      # whole-K 256 x 256 tiles on both paths: the planners may cut remainders differently
     outs = []
-    for asm, widen in (("1", "0"), ("0", "0"), ("0", "1")):
-        monkeypatch.setenv("RGN_W8_ASM", asm)
-        monkeypatch.setenv("RGN_W8_WIDEN_MIN_M", widen)
+    for asm in (-1, 0):
+        P.force(gemm_asm=asm)
         if epi == "gate":
             o = x.clone()
             ops.gemm(A, Wq, b, o, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=o)
@@ -895,7 +768,6 @@ def test_gemm_fp8_weights_in_the_hand_scheduled_loop_bit_identical_to_fp8_tile_a
         torch.cuda.synchronize()
         outs.append(o)
     assert torch.equal(outs[0], outs[1]), float((outs[0].float() - outs[1].float()).abs().max())
-    assert torch.equal(outs[0], outs[2]), float((outs[0].float() - outs[2].float()).abs().max())
     W = (Wq.float() * Wq._rgn_scale[:, None]).cpu()
     if epi == "bias":
         ref = F.linear(A.cpu().float(), W, b.cpu().float())
@@ -903,7 +775,7 @@ def test_gemm_fp8_weights_in_the_hand_scheduled_loop_bit_identical_to_fp8_tile_a
 
 
 @pytest.mark.parametrize("nsplit", [2, 3])
-def test_gemm_fp8_split_k_pieces_in_the_hand_scheduled_loop(nsplit, monkeypatch):
+def test_gemm_fp8_split_k_pieces_in_the_hand_scheduled_loop(nsplit):
     """Split-K remainder pieces on fp8 weights run the fp8 asm loop too (pieces of >= 4 K tiles): same result as the
     compiler-scheduled fp8 pieces at the same piece count."""
     from regione_amd import ops
@@ -912,11 +784,10 @@ def test_gemm_fp8_split_k_pieces_in_the_hand_scheduled_loop(nsplit, monkeypatch)
     A = bf(torch.randn(M, K, generator=g)).cuda()
     Wq = ops.quantize_w8((torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda())
     b = bf(torch.randn(N, generator=g)).cuda()
-    monkeypatch.setenv("RGN_GEMM_NSPLIT", str(nsplit))
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
+    P.force(gemm_pieces=nsplit, gemm_geometry=256)
     outs = []
-    for asm in ("1", "0"):
-        monkeypatch.setenv("RGN_W8_ASM", asm)
+    for asm in (-1, 0):
+        P.force(gemm_asm=asm)
         o = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         ops.gemm(A, Wq, b, o)
         torch.cuda.synchronize()
@@ -928,10 +799,10 @@ def test_gemm_fp8_split_k_pieces_in_the_hand_scheduled_loop(nsplit, monkeypatch)
 
 
 @pytest.mark.parametrize("case", ["gelu_576", "gate_288", "bias_ragged", "group_qkv", "fp8_gelu"])
-def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case, monkeypatch):
+def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case):
     """Round 3: the tiles of a launch that do not fill a whole round of the 256 workgroup slots run as QUADRANTS (128 x 128 blocks,
     two per CU) of the same tile list instead of being cut along K - no partials, no reduce pass, and per output element the same
-    accumulation order as an unsplit launch: RGN_GEMM_QUARTER=2 (forced) == RGN_GEMM_SPLIT=0 (one plain launch), bit for bit, for
+    accumulation order as an unsplit launch: gemm_quarter = 1 (forced) == gemm_pieces = 1 (one plain launch), bit for bit, for
     every epilogue, ragged edges, the fused Q/K/V epilogue of a two-branch group with gathered cache rows, and fp8 weights."""
     from regione_amd import ops
     g = torch.Generator().manual_seed(len(case))
@@ -959,18 +830,15 @@ def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case, mon
     if case != "group_qkv":
         _, fn, (M, N) = run()
         outs = []
-        for env in (dict(RGN_GEMM_QUARTER="2"), dict(RGN_GEMM_SPLIT="0", RGN_GEMM_QUARTER="0")):
-            for k in ("RGN_GEMM_QUARTER", "RGN_GEMM_SPLIT"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            o = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
-            fn(o)
-            torch.cuda.synchronize()
-            outs.append(o)
-            from regione_amd import _lib
-            plan = _lib.lib().rgn_gemm_last_plan()
-            assert bool(plan & 0x100) == ("RGN_GEMM_SPLIT" not in env), f"unexpected launch plan {plan:#x} under {env}"
+        from regione_amd import _lib
+        for env in (dict(gemm_quarter=1), dict(gemm_pieces=1, gemm_quarter=0)):
+            with _lib.plan_override(**env):
+                o = torch.full((M, N), 5.0, dtype=torch.bfloat16, device="cuda")
+                fn(o)
+                torch.cuda.synchronize()
+                outs.append(o)
+                plan = _lib.lib().rgn_gemm_last_plan()
+            assert bool(plan & 0x100) == ("gemm_pieces" not in env), f"unexpected launch plan {plan:#x} under {env}"
         assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0].float()).all()
         return
     # two CFG branches x (image, text) problems, fused Q/K/V epilogue, gathered cache rows on the image problems
@@ -983,11 +851,9 @@ def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case, mon
     Ai = [bf(torch.randn(Mi, K, generator=g)).cuda() for _ in Ts]
     At = [bf(torch.randn(t, K, generator=g)).cuda() for t in Ts]
     res = []
-    for env in (dict(RGN_GEMM_QUARTER="2"), dict(RGN_GEMM_SPLIT="0", RGN_GEMM_QUARTER="0")):
-        for k in ("RGN_GEMM_QUARTER", "RGN_GEMM_SPLIT"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    for env in (dict(gemm_quarter=1), dict(gemm_pieces=1, gemm_quarter=0)):
+        P.reset()
+        P.force(**env)
         probs, keep = [], []
         for b, T in enumerate(Ts):
             skv = T + S
@@ -1012,11 +878,11 @@ def test_gemm_quarter_tile_remainder_bit_identical_to_one_plain_launch(case, mon
 
 
 @pytest.mark.parametrize("Sq,Skv,H,w", [(256, 1024, 2, 1.0), (1536, 8704, 24, 1.3), (8704, 8704, 24, 1.0), (1408, 8576, 24, 2.5)])
-def test_attention_with_a_caller_guaranteed_score_bound_needs_no_running_max(Sq, Skv, H, w, monkeypatch):
+def test_attention_with_a_caller_guaranteed_score_bound_needs_no_running_max(Sq, Skv, H, w):
     """rgn_attention_bounded (round 3): q and k RMS-normalised per head and scaled by weights of magnitude <= w, so
     |q . k| / sqrt(128) <= sqrt(128) * w^2; with that bound the hand-scheduled kernel keeps no running row maximum
     (P = exp2(s * log2 e) directly).  Same softmax: against the fp32 reference < 1e-2 relative, and against the tracked-max
-    kernel (RGN_ATTN_STATIC_MAX=0) to bf16 rounding.  w = 2.5 -> bound * log2(e) = 102 > 96: the call falls back to the running
+    kernel (score_bound = 0) to bf16 rounding.  w = 2.5 -> bound * log2(e) = 102 > 96: the call falls back to the running
     max by itself (bit-identical to the unbounded call)."""
     from regione_amd import ops
     g = torch.Generator().manual_seed(Sq + H)
@@ -1039,16 +905,11 @@ def test_attention_with_a_caller_guaranteed_score_bound_needs_no_running_max(Sq,
     vt[:, pos] = v.T
     qc, kc, vc = q.cuda(), ks.cuda(), vt.cuda()
     outs = {}
-    for name, env, b in (("static", None, bound), ("tracked", "0", bound), ("unbounded", None, 0.0)):
-        if env is None:
-            monkeypatch.delenv("RGN_ATTN_STATIC_MAX", raising=False)
-        else:
-            monkeypatch.setenv("RGN_ATTN_STATIC_MAX", env)
+    for name, b in (("static", bound), ("tracked", 0.0)):          # score_bound = 0: the running-max loop
         o = torch.empty(Sq, D, dtype=torch.bfloat16).cuda()
         ops.attention(qc, kc, vc, o, Skv, H, score_bound=b)
         torch.cuda.synchronize()
         outs[name] = o.cpu()
-    assert torch.equal(outs["tracked"], outs["unbounded"])
     qq, kk, vv = (t.cuda().float().view(-1, H, 128).transpose(0, 1) for t in (q, k, v))
     s = torch.einsum("hqd,hkd->hqk", qq, kk) / math.sqrt(128.0)
     assert float(s.abs().max()) <= bound / 1.05 + 1e-3                   # the guarantee holds on these inputs
@@ -1061,7 +922,7 @@ def test_attention_with_a_caller_guaranteed_score_bound_needs_no_running_max(Sq,
 
 
 @pytest.mark.parametrize("variant", ["4", "8"])
-def test_attention_static_shift_at_the_ends_of_its_dynamic_range(variant, monkeypatch):
+def test_attention_static_shift_at_the_ends_of_its_dynamic_range(variant):
     """The rows the bounded softmax is argued safe for (attn.hip: static_m = 0, P = exp2(s * log2 e) within 2^+-96), which random
     draws never produce: with bound * log2(e) = 95.9, (i) a query ALIGNED with one key (s = +bound) and
     ANTI-ALIGNED with another (s = -bound) in the same row - P spans 2^+95.9 ... 2^-95.9 in one row sum; (ii) the mirrored query;
@@ -1069,7 +930,7 @@ def test_attention_static_shift_at_the_ends_of_its_dynamic_range(variant, monkey
     1024 * 2^-95.9 must not vanish and the output is the plain mean of V.  Checked against the fp32 softmax and against the
     tracked-max kernel; all finite."""
     from regione_amd import ops
-    monkeypatch.setenv("RGN_ATTN_VARIANT", variant)          # 8 = the 8-wave hand-scheduled kernel the pipeline runs, 4 = tiny query sets
+    P.force(attn_waves=int(variant))          # 8 = the 8-wave hand-scheduled kernel the pipeline runs, 4 = tiny query sets
     g = torch.Generator().manual_seed(5)
     Sq, Skv, H = 256, 1024, 2
     D = H * 128
@@ -1096,13 +957,9 @@ def test_attention_static_shift_at_the_ends_of_its_dynamic_range(variant, monkey
     vt = torch.zeros(D, pad, dtype=torch.bfloat16)
     vt[:, pos] = v.T
     outs = {}
-    for name, env in (("static", None), ("tracked", "0")):
-        if env is None:
-            monkeypatch.delenv("RGN_ATTN_STATIC_MAX", raising=False)
-        else:
-            monkeypatch.setenv("RGN_ATTN_STATIC_MAX", env)
+    for name, sb in (("static", bound), ("tracked", 0.0)):          # score_bound = 0: the running-max loop
         o = torch.empty(Sq, D, dtype=torch.bfloat16).cuda()
-        ops.attention(q.cuda(), ks.cuda(), vt.cuda(), o, Skv, H, score_bound=bound)
+        ops.attention(q.cuda(), ks.cuda(), vt.cuda(), o, Skv, H, score_bound=sb)
         torch.cuda.synchronize()
         outs[name] = o.cpu()
     ref = torch.einsum("hqk,hkd->hqd", torch.softmax(s.double(), -1), vv.double()).transpose(0, 1).reshape(Sq, D)
@@ -1138,9 +995,6 @@ def test_gemm_planner_long_k_region_shapes_take_the_256_geometry_with_split_k(Ms
     assert plan & (1 << 10), f"plan {plan:#x}: 128 geometry"
     assert not plan & (1 << 8), f"plan {plan:#x}: quarter-tile remainder"
     assert 3 <= (plan & 255) <= 5, plan & 255
-    os.environ["RGN_GEMM_SPLIT"] = "0"
-    try:
+    with ops._lib.plan_override(gemm_pieces=1):
         whole, _ = run()
-    finally:
-        del os.environ["RGN_GEMM_SPLIT"]
     assert rel_err(out.cpu(), whole.cpu()) < 2e-3

@@ -595,7 +595,7 @@ def test_degenerate_partitions_nothing_or_everything_edited(threshold, expect):
 def test_last_block_skips_rows_nothing_reads_same_result(family, monkeypatch):
     """harness/flux.py `out_rows`: the pipelines read only `[:, :latents.size(1)]` of a forward, so in a full step the last
     single block computes queries / MLP / attention / proj_out (and norm_out / proj_out) for the latent rows only.  Same
-    latents and ids as with every row computed like the reference does (RGN_SKIP_UNREAD_ROWS=0), RegionE on and off; a direct
+    latents and ids as with every row computed like the reference does (harness.flux.SKIP_UNREAD_ROWS = False), RegionE on and off; a direct
     transformer call without the hint still returns every row."""
     from regione_amd.harness import step1x as HS
     h = w = 16
@@ -791,7 +791,7 @@ def test_cfg_branches_batched_through_one_pass_bit_identical_to_two_forwards(fam
     # "0": two forwards
     for batched in ("1", "1s", "0"):
         monkeypatch.setenv("RGN_BATCH_BRANCHES", batched[0])
-        monkeypatch.setenv("RGN_ATTN_BRANCH_STREAMS", "0" if batched == "1s" else "1")
+        monkeypatch.setattr(H, "ATTN_BRANCH_STREAMS", batched != "1s")
         van = pipe(**kw)[0].clone()
         helper.enable()
         trace = {}

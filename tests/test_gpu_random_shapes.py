@@ -87,13 +87,13 @@ def test_gemm_random_shapes_strides_and_epilogues(seed):
 @pytest.mark.parametrize("seed", range(6))
 def test_gemm_random_groups_match_separate_launches(seed, split, monkeypatch):
     """rgn_gemm_group: 2 - 4 problems (random row counts incl. tiny ones, shared or own weights) against one launch per problem:
-    bit-identical without the split-K schedule (RGN_GEMM_SPLIT=0: tile-local arithmetic does not depend on the grouping); with it
+    bit-identical without the split-K schedule (gemm_pieces = 1: tile-local arithmetic does not depend on the grouping); with it
     the merged launch may cut a remainder into a different number of K pieces than the single launch does (fp32 summation order),
     so the two agree to one bf16 rounding and both sit within tolerance of the fp64 reference."""
     import numpy as np
     from regione_amd import ops
     if split is not None:
-        monkeypatch.setenv("RGN_GEMM_SPLIT", split)
+        ops._lib.lib().rgn_plan_override(b"gemm_pieces", 1)          # reset after the test (conftest)
     rng = np.random.default_rng(2000 + seed)
     g = torch.Generator(device="cuda").manual_seed(100 + seed)
     for case in range(6):

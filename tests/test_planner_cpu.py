@@ -19,9 +19,10 @@ def plan(Ms, N, K, distinct_w=None, w8=0, ws=WS):
 
 
 @pytest.fixture(autouse=True)
-def no_switches(monkeypatch):
-    for k in ("RGN_GEMM_VARIANT", "RGN_GEMM_NSPLIT", "RGN_GEMM_QUARTER", "RGN_GEMM_SPLIT", "RGN_W8_ASM"):
-        monkeypatch.delenv(k, raising=False)
+def no_overrides():
+    _lib.lib().rgn_plan_override(None, 0)          # every knob at -1: the cost models decide
+    yield
+    _lib.lib().rgn_plan_override(None, 0)
 
 
 @pytest.mark.parametrize("Ms,N,K", [((1137,), 3072, 15360), ((1056,), 3072, 15360), ((1248,), 3072, 15360),
@@ -54,14 +55,17 @@ def test_full_step_projection_keeps_whole_rounds_and_splits_the_remainder():
     assert plan((8704,), 21504, 3072) == dict(big=True, pieces=1, quarter=False)
 
 
-def test_no_workspace_means_no_split_and_switches_are_honoured(monkeypatch):
+def test_no_workspace_means_no_split_and_overrides_are_honoured():
     assert plan((1536,), 3072, 15360, ws=0)["pieces"] <= 1          # no partials without a workspace (here: the 128 geometry instead)
     assert plan((8704,), 3072, 15360, ws=0) == dict(big=True, pieces=1, quarter=False)
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "1")
-    assert not plan((1536,), 3072, 15360)["big"]
-    monkeypatch.setenv("RGN_GEMM_VARIANT", "3")
-    monkeypatch.setenv("RGN_GEMM_NSPLIT", "5")
-    assert plan((1536,), 3072, 15360) == dict(big=True, pieces=5, quarter=False)
+    with _lib.plan_override(gemm_geometry=128):
+        assert not plan((1536,), 3072, 15360)["big"]
+    with _lib.plan_override(gemm_geometry=256, gemm_pieces=5):
+        assert plan((1536,), 3072, 15360) == dict(big=True, pieces=5, quarter=False)
+    with _lib.plan_override(gemm_pieces=1):
+        assert plan((8704,), 3072, 15360) == dict(big=True, pieces=1, quarter=False)
+    assert plan((1536,), 3072, 15360) == dict(big=True, pieces=3, quarter=False)          # the knobs are back at -1
+    assert _lib.lib().rgn_plan_override(b"no_such_knob", 1) < 0
 
 
 def test_bad_arguments_are_refused():
@@ -81,12 +85,6 @@ def aplan(Sq, Skv, H=24, ws=128 << 20):
     return dict(pieces=p & 15, stream_k=bool(p & 16), waves8=bool(p & 32))
 
 
-@pytest.fixture(autouse=True)
-def no_attention_switches(monkeypatch):
-    for k in ("RGN_ATTN_VARIANT", "RGN_ATTN_STREAMK", "RGN_ATTN_ASM"):
-        monkeypatch.delenv(k, raising=False)
-
-
 @pytest.mark.parametrize("Sq,Skv,want", [
     (1536, 8704, dict(pieces=1, stream_k=True, waves8=True)),        # FLUX region step at K_e 25 %: 144 items -> stream-K (171 vs 176 / 182 us)
     (1137, 8704, dict(pieces=2, stream_k=False, waves8=True)),       # K_e 15 %: 120 items x 2 equal pieces = one round (126 vs 149 us stream-K)
@@ -98,14 +96,17 @@ def test_attention_remainder_schedules(Sq, Skv, want):
     assert aplan(Sq, Skv) == want
 
 
-def test_attention_plan_switches_and_small_query_sets(monkeypatch):
+def test_attention_plan_overrides_and_small_query_sets():
     assert not aplan(576, 8704)["waves8"]                            # 72 items of 256 rows < 96: 4-wave workgroups of 128 rows
     assert aplan(1536, 8704, ws=0) == dict(pieces=1, stream_k=False, waves8=True)     # no workspace: no partials
-    monkeypatch.setenv("RGN_ATTN_STREAMK", "0")
-    p = aplan(1536, 8704)
-    assert not p["stream_k"]
-    monkeypatch.setenv("RGN_ATTN_STREAMK", "2")
-    assert aplan(1137, 8704)["stream_k"]
+    with _lib.plan_override(attn_streamk=0):
+        assert not aplan(1536, 8704)["stream_k"]
+    with _lib.plan_override(attn_streamk=1):
+        assert aplan(1137, 8704)["stream_k"]
+    with _lib.plan_override(attn_split=0):
+        assert aplan(1536, 8704) == dict(pieces=1, stream_k=False, waves8=True)
+    with _lib.plan_override(attn_waves=4):
+        assert not aplan(1536, 8704)["waves8"]
     assert _lib.lib().rgn_attention_plan_query(0, 8704, 24, 0) < 0
 
 

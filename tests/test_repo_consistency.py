@@ -19,12 +19,23 @@ def test_committed_counter_files_carry_the_stamp_of_the_committed_kernel_sources
     sys.path.insert(0, ROOT)
     import bench
     stamp = bench.csrc_hash()
-    for name in ("r04_pmc_traffic.json", "r04_pmc_mfma.json"):
-        assert json.loads(_read("profiles", name))["csrc_sha16"] == stamp, (name, stamp)
-    assert stamp in _read("profiles", "README_r04.md")
+    import pytest
+    if not all(os.path.exists(os.path.join(ROOT, n)) for n in (bench.PMC_TRAFFIC_FILE, bench.PMC_MFMA_FILE)):
+        pytest.skip("no counter pass of this round committed yet (tools/probes/measure_counters.sh)")
+    for name in (bench.PMC_TRAFFIC_FILE, bench.PMC_MFMA_FILE):
+        assert json.loads(_read(name))["csrc_sha16"] == stamp, (name, stamp)
+    # and a file with another stamp is NOT quoted
+    assert bench.load_stamped(bench.PMC_TRAFFIC_FILE, stamp="0" * 16) == {}
+    assert bench.load_stamped(bench.PMC_TRAFFIC_FILE).get("csrc_sha16") == stamp
 
 
-def test_every_environment_switch_the_code_reads_is_documented():
+def test_the_shipped_library_reads_one_environment_variable_and_every_switch_is_documented():
+    """no per-launch getenv, <= 6 documented switches, A/B scaffolding out of the product."""
+    n_getenv = 0
+    for fn in os.listdir(os.path.join(ROOT, "regione_amd", "csrc")):
+        if fn.endswith((".hip", ".h", ".inc", ".cpp")):
+            n_getenv += len(re.findall(r"\bgetenv\(", _read("regione_amd", "csrc", fn)))
+    assert n_getenv == 1, n_getenv                                  # RGN_PLAN_OVERRIDE, parsed once (region.hip: plan_override())
     pat = re.compile(r"(?:getenv\(\s*|environ\.get\(\s*|environ\[\s*)\"(RGN_[A-Z0-9_]+)\"")
     used = set()
     for base, _, files in os.walk(os.path.join(ROOT, "regione_amd")):
@@ -32,11 +43,12 @@ def test_every_environment_switch_the_code_reads_is_documented():
             if fn.endswith((".py", ".hip", ".cpp", ".h")):
                 used |= set(pat.findall(_read(base, fn)))
     used |= set(pat.findall(_read("bench.py")))
-    assert len(used) >= 20
+    assert used == {"RGN_LIB", "RGN_TORCH_OPS", "RGN_BATCH_BRANCHES", "RGN_BRANCH_STREAMS", "RGN_PLAN_OVERRIDE"}, sorted(used)
     doc = _read("INTEGRATION.md")
-    missing = sorted(v for v in used if v not in doc)
-    # RGN_GEMM_DBG exists only in -DRGN_TIMING_PROBES builds and is described as such
-    assert missing in ([], ["RGN_GEMM_DBG"]), missing
+    assert all(v in doc for v in used)
+    # every launch-plan knob the library knows is in the table too
+    from regione_amd import _lib
+    assert all(f"`{k}`" in doc for k in _lib.PLAN_KEYS)
 
 
 def test_design_md_stays_under_40_kib():

@@ -57,7 +57,7 @@ def bench_gemm():
             state["i"] = (state["i"] + 1) % len(Ws)
             ops.gemm(A, Ws[state["i"]], b, out)
         for variant in VARIANTS:
-            os.environ["RGN_GEMM_VARIANT"] = variant
+            force(GEOM[variant])
             med, best = timeit(run)
             fl = 2.0 * M * N * K
             print(f"gemm[{variant:>4}] {name:<18} M={M:<5} N={N:<6} K={K:<6} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
@@ -98,7 +98,7 @@ def bench_small():
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         x, gate = rnd(M, N), rnd(N)
         for variant in VARIANTS:
-            os.environ["RGN_GEMM_VARIANT"] = variant
+            force(GEOM[variant])
             if gated:
                 med, best = timeit(lambda: ops.gemm(A, nxt(Ws), b, x, epilogue=ops.EPI_GATE_RESID, gate=gate, resid=x))
             else:
@@ -112,7 +112,7 @@ def bench_small():
         W0s, W1s = copies(W0), copies(W1)
         o0, o1 = torch.empty(M0, N, dtype=torch.bfloat16, device="cuda"), torch.empty(M1, N, dtype=torch.bfloat16, device="cuda")
         for variant in VARIANTS:
-            os.environ["RGN_GEMM_VARIANT"] = variant
+            force(GEOM[variant])
             if gated:
                 x0, x1, gate = rnd(M0, N), rnd(M1, N), rnd(N)
                 med, best = timeit(lambda: ops.gemm_pair(A0, nxt(W0s), b, x0, A1, W1s[st["i"]], b, x1, epilogue=ops.EPI_GATE_RESID,
@@ -125,7 +125,7 @@ def bench_small():
 
 def bench_w8():
     """fp8 (e4m3fn) weights: bf16 weights vs the three fp8 paths - tiles inside the hand-scheduled loop (round 3 default),
-    compiler-scheduled fp8 tiles (RGN_W8_ASM=0), widen-once (RGN_W8_WIDEN_MIN_M=1) - cold weights (every launch a different copy)."""
+    compiler-scheduled fp8 tiles (gemm_asm = 0) - cold weights (every launch a different copy)."""
     shapes = [("v1p2 R kvq+mlp x2", 9088, 21504, 3072), ("v1p2 R proj_out x2", 9088, 3072, 15360), ("v1p2 F kvq+mlp", 33280, 21504, 3072),
               ("v1p2 F proj_out", 33280, 3072, 15360), ("R kvq+mlp", 1536, 21504, 3072), ("R proj_out", 1536, 3072, 15360),
               ("R5% kvq+mlp", 708, 21504, 3072), ("R5% proj_out", 708, 3072, 15360)]
@@ -144,13 +144,9 @@ def bench_w8():
             st["i"] = (st["i"] + 1) % len(Ws)
             ops.gemm(A, Ws[st["i"]], b, out)
         fl = 2.0 * M * N * K
-        rows = [("bf16 W", W16, {}), ("fp8 asm loop", W8, dict(RGN_W8_ASM="1", RGN_W8_WIDEN_MIN_M="0")),
-                ("fp8 compiler tiles", W8, dict(RGN_W8_ASM="0", RGN_W8_WIDEN_MIN_M="0")),
-                ("fp8 widen once", W8, dict(RGN_W8_ASM="0", RGN_W8_WIDEN_MIN_M="1"))]
+        rows = [("bf16 W", W16, {}), ("fp8 asm loop", W8, {}), ("fp8 compiler tiles", W8, dict(gemm_asm=0))]
         for label, Ws, env in rows:
-            for k in ("RGN_W8_ASM", "RGN_W8_WIDEN_MIN_M"):
-                os.environ.pop(k, None)
-            os.environ.update(env)
+            force(env)
             med, best = timeit(lambda: run(Ws), iters=5, inner=15)
             print(f"w8 {name:<20} M={M:<6} N={N:<6} K={K:<6} {label:<20} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF")
         del W16, W8, A, out
@@ -198,7 +194,7 @@ def bench_attn():
         q, k, vt = rnd(Sq, D), rnd(Skv, D), rnd(D, Skv)
         out = torch.empty_like(q)
         for variant in AVARIANTS:
-            os.environ["RGN_ATTN_VARIANT"] = variant
+            force(AGEOM[variant])
             med, best = timeit(lambda: ops.attention(q, k, vt, out, Skv, H))
             fl = 4.0 * Sq * Skv * D
             print(f"attn[{variant:>4}] {name:<12} Sq={Sq:<5} Skv={Skv:<5} {med*1e3:8.1f} us  {fl/med/1e9:7.1f} TF (best {fl/best/1e9:7.1f})")
@@ -211,7 +207,19 @@ def bench_gemv():
     print(f"gemv modulation N={N} K={K}: {med*1e3:.1f} us  {N*K*2/med/1e9:.2f} TB/s")
 
 
-VARIANTS = os.environ.get("GEMM_VARIANTS", "auto").split(",")
+GEOM = {"auto": {}, "128": dict(gemm_geometry=128), "256c": dict(gemm_geometry=256, gemm_asm=0), "256": dict(gemm_geometry=256)}
+AGEOM = {"auto": {}, "8": dict(attn_waves=8), "8n": dict(attn_waves=8, attn_split=0), "4": dict(attn_waves=4), "4n": dict(attn_waves=4, attn_split=0)}
+
+
+def force(knobs):
+    """Launch-plan knobs for the following launches (rgn_plan_override): every knob back to -1 first."""
+    from regione_amd import _lib
+    _lib.lib().rgn_plan_override(None, 0)
+    for k, v in knobs.items():
+        _lib.check(_lib.lib().rgn_plan_override(k.encode(), int(v)), k)
+
+
+VARIANTS = os.environ.get("GEMM_VARIANTS", "auto").split(",")          # auto | 128 | 256c (compiler-scheduled) | 256
 AVARIANTS = os.environ.get("ATTN_VARIANTS", "auto").split(",")   # e.g. 8,8n,4,4n (n = no KV split)
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "gemv"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Shader clock / power under sustained load of one kernel (GPU box only): queues ~2 s of back-to-back
-launches and polls rocm-smi while the GPU drains them.   python tools/clock_probe.py [attn|gemm|vendor|idle]"""
+launches and polls rocm-smi while the GPU drains them.   python tools/clock_probe.py [attn|gemm|vendor|vendor_attn|vendor_attn_region|attn_region|edit|idle] [--json]"""
 import sys, os, subprocess, time, re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -65,6 +65,9 @@ def summarise(what, samples, us_per_launch, flops_per_launch):
     return rec
 
 
+FLOPS_OVERRIDE = {}
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "attn"
     as_json = "--json" in sys.argv
@@ -88,6 +91,21 @@ def main():
         A, W, b = rnd(8704, 3072), rnd(21504, 3072) * 0.05, rnd(21504)
         out = torch.empty(8704, 21504, dtype=torch.bfloat16, device="cuda")
         fn, n = (lambda: torch.addmm(b, A, W.t(), out=out)), 2000
+    elif what in ("vendor_attn", "vendor_attn_region", "attn_region"):
+        # the vendor measuring stick for attention (verdict r4 item 1a): torch's scaled_dot_product_attention on ROCm (flash /
+        # CK / AOTriton backend, whatever this build dispatches to) on the SAME problem - 24 heads x 128, Skv 8704, bf16,
+        # non-causal - at the full-step (Sq 8704) and the region-step (Sq 1536) query counts; `attn_region` = ours at Sq 1536
+        import torch.nn.functional as F
+        H, S = 24, 8704
+        Sq = S if what == "vendor_attn" else 1536
+        if what == "attn_region":
+            q, k, vt = rnd(Sq, H * 128), rnd(S, H * 128), rnd(H * 128, S)
+            out = torch.empty_like(q)
+            fn, n = (lambda: ops.attention(q, k, vt, out, S, H)), 6000
+        else:
+            q, k, v = rnd(1, H, Sq, 128), rnd(1, H, S, 128), rnd(1, H, S, 128)
+            fn, n = (lambda: F.scaled_dot_product_attention(q, k, v)), (600 if Sq == S else 3000)
+        FLOPS_OVERRIDE[what] = 4.0 * Sq * S * H * 128
     else:
         fn, n = (lambda: None), 0
     print("idle     sclk/mclk/W:", smi())
@@ -106,7 +124,7 @@ def main():
     torch.cuda.synchronize()
     if n:
         us = s.elapsed_time(e) / n * 1e3
-        flops = {"attn": 4.0 * 8704 * 8704 * 3072, "gemm": 2.0 * 8704 * 21504 * 3072, "vendor": 2.0 * 8704 * 21504 * 3072}.get(what)
+        flops = {"attn": 4.0 * 8704 * 8704 * 3072, "gemm": 2.0 * 8704 * 21504 * 3072, "vendor": 2.0 * 8704 * 21504 * 3072, **FLOPS_OVERRIDE}.get(what)
         if as_json:
             import json
             print(json.dumps(summarise(what, samples, us, flops)))

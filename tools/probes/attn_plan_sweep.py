@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Does attention_schedule (attn.hip) pick the fastest remainder schedule for the region-step query counts?  For Sq = T + K_e across K_e
 and the KV lengths of the three resolutions, time the schedules the library can be switched into: auto | equal KV split only
-(RGN_ATTN_STREAMK=0) | stream-K forced (=2) | no split (RGN_ATTN_VARIANT=8n).  Rotating K/V slabs; GPU box only, measurement tool."""
+(attn_streamk = 0) | stream-K forced (= 1) | no split (attn_split = 0).  Rotating K/V slabs; GPU box only, measurement tool."""
 import os
 import sys
 
@@ -11,11 +11,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
 from regione_amd import ops  # noqa: E402
-from bench_kernels import timeit, rnd  # noqa: E402
+from bench_kernels import timeit, rnd, force  # noqa: E402
 
 H = 24
 D = H * 128
-MODES = [("auto", {}), ("equal split", {"RGN_ATTN_STREAMK": "0"}), ("stream-K", {"RGN_ATTN_STREAMK": "2"}), ("no split", {"RGN_ATTN_VARIANT": "8n"})]
+MODES = [("auto", {}), ("equal split", dict(attn_streamk=0)), ("stream-K", dict(attn_streamk=1)), ("no split", dict(attn_waves=8, attn_split=0))]
 
 
 def main():
@@ -37,12 +37,9 @@ def main():
                 run()
             res = {}
             for name, env in MODES:
-                for k in ("RGN_ATTN_STREAMK", "RGN_ATTN_VARIANT"):
-                    os.environ.pop(k, None)
-                os.environ.update(env)
+                force(env)
                 res[name] = timeit(run, iters=5, warm=2, inner=20)[0] * 1e3
-            for k in ("RGN_ATTN_STREAMK", "RGN_ATTN_VARIANT"):
-                os.environ.pop(k, None)
+            force({})
             best = min((n for n in res if n != "auto"), key=lambda n: res[n])
             fl = 4.0 * Sq * Skv * D
             print(f"{label} Skv={Skv:<5} Sq={Sq:<5} items={H * ((Sq + 255) // 256):<4} auto {res['auto']:7.1f} us ({fl / res['auto'] / 1e6:6.0f} TF) | "

@@ -21,10 +21,11 @@ import torch  # noqa: E402
 from regione_amd import ops, _lib  # noqa: E402
 from bench_kernels import timeit, rnd  # noqa: E402
 
-ENV_KEYS = ("RGN_GEMM_VARIANT", "RGN_GEMM_NSPLIT", "RGN_GEMM_QUARTER", "RGN_GEMM_SPLIT")
-SCHEDULES = [("auto", {}), ("128", {"RGN_GEMM_VARIANT": "1"}), ("256 plain", {"RGN_GEMM_VARIANT": "3", "RGN_GEMM_SPLIT": "0"})]
-SCHEDULES += [(f"256 S={s}", {"RGN_GEMM_VARIANT": "3", "RGN_GEMM_NSPLIT": str(s)}) for s in range(2, 9)]
-SCHEDULES += [("256 quarter", {"RGN_GEMM_VARIANT": "3", "RGN_GEMM_QUARTER": "2"})]
+from bench_kernels import force  # noqa: E402  (rgn_plan_override: the launch-plan knobs, include/regione_hip.h)
+
+SCHEDULES = [("auto", {}), ("128", dict(gemm_geometry=128)), ("256 plain", dict(gemm_geometry=256, gemm_pieces=1))]
+SCHEDULES += [(f"256 S={s}", dict(gemm_geometry=256, gemm_pieces=s)) for s in range(2, 9)]
+SCHEDULES += [("256 quarter", dict(gemm_geometry=256, gemm_quarter=1))]
 
 
 def shapes(dense=False, full=False):
@@ -94,14 +95,11 @@ def main():
         for _ in range(40):                 # clocks / allocator settled before the first schedule (auto) is timed
             run()
         for label, env in SCHEDULES:
-            for k in ENV_KEYS:
-                os.environ.pop(k, None)
-            os.environ.update(env)
+            force(env)
             med, best = timeit(run, iters=5, warm=2, inner=20)
             plan = _lib.lib().rgn_gemm_last_plan()
             res[label] = dict(us=med * 1e3, plan=plan)
-        for k in ENV_KEYS:
-            os.environ.pop(k, None)
+        force({})
         fl = 2.0 * sum(Ms) * N * K
         auto = res["auto"]
         best_label = min((l for l in res if l != "auto"), key=lambda l: res[l]["us"])

@@ -141,7 +141,7 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
                full_token_edit_s=tv, full_token_steps_per_s=steps / tv, speedup=tv / tr_s,
                latent_psnr_vs_full_token_random_weights_db=float(O.psnr(out.cpu(), van.cpu())), cfg_scale=cfg_scale,
                peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30, weights="fp8 e4m3fn + per-channel scale" if fp8 else "bf16")
-    # GPU time per denoising step by kind (an event at every callback_on_step_end), and - RGN_CFG_KTIMER=1 - the per-shape
+    # GPU time per denoising step by kind (an event at every callback_on_step_end), and - `--ktimer` - the per-shape
     # launch table of one more edit (HIP events around every GEMM / attention launch, like bench.py)
     evs = [torch.cuda.Event(enable_timing=True)]
     evs[0].record()
@@ -158,7 +158,7 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
     for k, m in zip(tr2["kind"], [a.elapsed_time(b) for a, b in zip(evs[:-1], evs[1:])]):
         by.setdefault(k, []).append(m)
     res["step_ms_by_kind"] = {k: dict(n=len(v), avg_ms=round(sum(v) / len(v), 3), min_ms=round(min(v), 3)) for k, v in by.items()}
-    if os.environ.get("RGN_CFG_KTIMER"):
+    if KTIMER:
         from regione_amd import ops
         kt = B.KernelTimer()
         kt.wrap(ops)
@@ -190,10 +190,16 @@ def run_case(name, family, size, frac, device, cfg_scale=None, T=512, Tn=None, t
     return res
 
 
+KTIMER = False
+
+
 CASES = {
     "flux_sweep": [("flux_1024_ke%02d" % int(f * 100), "flux", 1024, f, {}) for f in (0.05, 0.15, 0.25, 0.50)],
     "flux_cfg": [("flux_1024_truecfg6_ke25 (configs[3], one rank's image)", "flux", 1024, 0.25, dict(cfg_scale=6.0))],
     "step1x_512": [("step1x_v1p1_512_cfg6 (configs[0] on the GPU)", "step1x", 512, 0.25, dict(cfg_scale=6.0))],
+    # the reference's own headline row: Step1X-Edit v1p1 at 1024^2, 2.572x (assets/result.jpg, README.md:23) - K_e 15 / 25 % here
+    "step1x_1024": [("step1x_v1p1_1024_cfg6_ke%02d (the reference's published 2.572x configuration)" % int(f * 100), "step1x", 1024, f,
+                     dict(cfg_scale=6.0, vanilla_runs=1)) for f in (0.15, 0.25)],
     "step1x_v1p2_2048": [("step1x_v1p2_2048_cfg6 bf16 28 steps (configs[4] shape at 28 steps)", "step1x_v1p2",
                           2048, 0.25, dict(cfg_scale=6.0, Tn=384, vanilla_runs=1))],
     "step1x_v1p2_2048_50": [("step1x_v1p2_2048_cfg6 bf16 50 steps, gamma re-sampled to 49 entries (configs[4] on bf16 weights)",
@@ -218,7 +224,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("step1x_v1p2_2048_50") and c not in ("qwen_sweep", "qwen_quick", "flux_cfg_quick")])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--ktimer", action="store_true", help="per-shape launch table of one more edit (HIP events around every GEMM / attention launch)")
     args = ap.parse_args()
+    global KTIMER
+    KTIMER = args.ktimer
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     results = []
