@@ -260,6 +260,18 @@ int rgn_rms_norm_rows(const void* x, int ldx, const void* w, void* out, int ldo,
 /* y = bf16(silu(x)) elementwise on bf16 (F.silu of the AdaLN conditioning vector). */
 int rgn_silu_bf16(const void* x, void* y, size_t n, void* stream);
 
+/* y = bf16(a + b) elementwise on bf16 (fp32 add, one rounding = torch's bf16 add): `timesteps_emb + guidance_emb`, `+ pooled_projections`
+ * of CombinedTimestepGuidanceTextProjEmbeddings [EXT] (call site inplace.py:476-480).  y may alias a or b. */
+int rgn_add_bf16(const void* a, const void* b, void* y, size_t n, void* stream);
+
+/* out[i] = i (i < T), out[T + k] = T + edited_ids[k]: the cache rows [text ; T + edited ids] a region step rewrites -
+ * `selection = torch.cat((arange(txt_len), edited_ids + txt_len))`, inplace.py:732-733.  out: int64 [T + K]. */
+int rgn_sel_rows(const int64_t* edited_ids, int K, int T, int64_t* out, void* stream);
+
+/* hipMemsetAsync(ptr, 0, bytes) on `stream`: zero-initialises a K / V^T cache slab (the padding rows up to skv_pad must be finite;
+ * the reference's caches have no padding) without a torch fill kernel. */
+int rgn_fill_zero(void* ptr, size_t bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * LayerNorm(eps, no affine) * (1 + scale) + shift over rows of width d (AdaLN-Zero modulate).
  * Rows < split_row use (shift0, scale0), the others (shift1, scale1) - the text / image streams

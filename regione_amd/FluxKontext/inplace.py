@@ -141,7 +141,7 @@ class RegionEFluxKontextPipeline(H.FluxKontextPipeline):
             else:
                 latent_model_input = latents
                 if MANAGER.is_full_input_step():                                # inplace.py:331-332
-                    latent_model_input = torch.cat([latents, image_latents], dim=1)
+                    latent_model_input = H.cat_tokens(self.transformer, latents, image_latents)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
 
                 def branch(embeds, pooled_e, tag):
@@ -281,8 +281,8 @@ class RegionEFluxAttnProcessor(H.FluxAttnProcessor):
                 cur = torch.cuda.current_stream(ws.device)
                 dflt = torch.cuda.default_stream(ws.device)
                 with torch.cuda.stream(dflt):
-                    c = (torch.zeros(pad, d, dtype=torch.bfloat16, device=ws.device),
-                         torch.zeros(d, pad, dtype=torch.bfloat16, device=ws.device), skv)
+                    c = (ops.zeros((pad, d), dtype=torch.bfloat16, device=ws.device),
+                         ops.zeros((d, pad), dtype=torch.bfloat16, device=ws.device), skv)
                 cur.wait_stream(dflt)            # the zero fill is ordered before this forward's writes
                 if cur != dflt:
                     c[0].record_stream(cur)

@@ -127,8 +127,7 @@ class FluxKontextManager:
     # `selection` of Step1XEditV1P2/inplace.py:833,868)
     def sel_rows_for(self, T: int) -> torch.Tensor:
         if T not in self._sel_by_T:
-            dev = self.edited_ids.device
-            self._sel_by_T[T] = torch.cat((torch.arange(T, device=dev), self.edited_ids.squeeze(0) + T)).contiguous()
+            self._sel_by_T[T] = ops.sel_rows(self.edited_ids.squeeze(0), T)          # rgn_sel_rows: one launch
         return self._sel_by_T[T]
 
     def rope_q_for(self, T: int, full_table):

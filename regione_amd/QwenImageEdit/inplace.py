@@ -105,7 +105,7 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
             else:
                 x = latents
                 if MANAGER.is_full_input_step():                                         # :364-365
-                    x = torch.cat([latents, image_latents], dim=1)
+                    x = H.cat_tokens(self.transformer, latents, image_latents)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
                 def branch(embeds, tag):
                     tr.out_rows_hint = latents.size(1)

@@ -96,7 +96,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipeline):
             else:
                 x = latents
                 if MANAGER.is_full_input_step():                                    # :378-379
-                    x = torch.cat([latents, image_latents], dim=1)
+                    x = H.cat_tokens(self.transformer, latents, image_latents)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
                 assert do_true_cfg, "the reference leaves noise_pred undefined without true CFG (:381-399)"
                 xb, pe = self._batched_inputs(x, prompt_embeds, negative_prompt_embeds)

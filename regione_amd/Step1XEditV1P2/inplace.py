@@ -98,7 +98,7 @@ class RegionEStep1XEditPipeline(HS.Step1XEditPipelineV1P2):
             else:
                 x = latents
                 if MANAGER.is_full_input_step():
-                    x = torch.cat([latents, image_latents], dim=1)
+                    x = H.cat_tokens(self.transformer, latents, image_latents)
                 timestep = t.expand(latents.shape[0]).to(latents.dtype)
                 def branch(embeds, ids, tag):                                                                       # :388-419
                     tr.out_rows_hint = latents.size(1)

@@ -89,6 +89,9 @@ SIGNATURES = {
                       _c_void_p],
     "rgn_rms_norm_rows": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "rgn_silu_bf16": [_c_void_p, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_add_bf16": [_c_void_p, _c_void_p, _c_void_p, C.c_size_t, _c_void_p],
+    "rgn_sel_rows": [_c_void_p, _c_int, _c_int, _c_void_p, _c_void_p],
+    "rgn_fill_zero": [_c_void_p, C.c_size_t, _c_void_p],
     "rgn_ln_modulate": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "rgn_ln_modulate_segs": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_float, _c_int, C.POINTER(_c_int),

@@ -334,6 +334,13 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
             if think[k]:
                 raise NotImplementedError(f"{_host_name(host)}.__call__: {k}=True (the VLM thinking / reflection retry loop, "
                                           "Step1XEditV1P2/inplace.py:192-212) is not hosted by the HIP loop; pass False")
+        if enable_reflection_mode is None:
+            # the reference's signature default is reflection ON (Step1XEditV1P2/inplace.py:108): a caller that leaves it unspecified
+            # gets ONE attempt here - say so instead of deviating silently (advisor finding, round 4)
+            import warnings
+            warnings.warn(f"{_host_name(host)}.__call__: enable_reflection_mode left unspecified - the reference defaults to True (a VLM "
+                          "reflection retry loop), the HIP-hosted call runs ONE attempt without reflection; pass "
+                          "enable_reflection_mode=False to acknowledge", stacklevel=3)
     else:                                   # v1p1 has no such arguments: a caller passing them gets the usual refusal
         unused = dict(unused, **{k: v for k, v in think.items() if v is not None})
     _refuse_unused(_host_name(host) + ".__call__", unused)

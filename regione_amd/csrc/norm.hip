@@ -192,11 +192,27 @@ __global__ void silu_bf16_kernel(const uint16_t* __restrict__ x, uint16_t* __res
     }
 }
 
+// y = bf16(a + b) elementwise on bf16 (fp32 add, one rounding: what torch's bf16 add computes) - the two adds of
+// CombinedTimestepGuidanceTextProjEmbeddings [EXT]; the result may alias an input
+__global__ void add_bf16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+
 }  // namespace rgn
 
 using namespace rgn;
 
 extern "C" {
+
+int rgn_add_bf16(const void* a, const void* b, void* y, size_t n, void* stream) {
+    if (n == 0) return 0;
+    if (!a || !b || !y) return fail(RGN_E_BADARG, "add: null pointer");
+    size_t g = (n + 255) / 256;
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)a, (const uint16_t*)b, (uint16_t*)y, n);
+    return check_launch("add_bf16_kernel");
+}
 
 int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int split_row,
                     const void* shift0, const void* scale0, const void* shift1, const void* scale1, void* stream) {

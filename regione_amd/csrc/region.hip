@@ -312,6 +312,14 @@ static int launch_morph(const uint8_t* raw, int H, int W, int ed, int64_t* e, in
 
 // the launch-plan override table (common.h): all -1 unless RGN_PLAN_OVERRIDE="key=value,..." names fields - the library's only
 // environment read, once per process
+// sel[i] = i for the T text rows, sel[T + k] = T + edited_ids[k]: the cache rows a region step rewrites (`selection` of
+// inplace.py:732-733: torch.cat((arange(T), edited_ids + T)) - three eager launches in the reference)
+__global__ void sel_rows_kernel(const int64_t* __restrict__ ids, int K, int T, int64_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T) out[i] = i;
+    else if (i < T + K) out[i] = (int64_t)T + ids[i - T];
+}
+
 static bool plan_set(PlanOverride& o, const char* key, int value) {
     struct { const char* name; int* field; } tab[] = {
         {"gemm_pieces", &o.gemm_pieces}, {"gemm_geometry", &o.gemm_geometry}, {"gemm_asm", &o.gemm_asm}, {"gemm_quarter", &o.gemm_quarter},
@@ -348,6 +356,20 @@ extern "C" {
 
 int rgn_version(void) { return RGN_ABI_VERSION; }
 size_t rgn_abi_struct_bytes(void) { return sizeof(rgn_qkv_epilogue) * 1000 + sizeof(rgn_gemm_problem); }
+
+int rgn_sel_rows(const int64_t* edited_ids, int K, int T, int64_t* out, void* stream) {
+    if (K < 0 || T < 0 || (K > 0 && !edited_ids) || !out) return fail(RGN_E_BADARG, "sel_rows: bad argument");
+    if (T + K == 0) return 0;
+    hipLaunchKernelGGL(sel_rows_kernel, dim3((T + K + 255) / 256), dim3(256), 0, (hipStream_t)stream, edited_ids, K, T, out);
+    return check_launch("sel_rows_kernel");
+}
+
+int rgn_fill_zero(void* ptr, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    if (!ptr) return fail(RGN_E_BADARG, "fill_zero: null pointer");
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
 
 int rgn_plan_override(const char* key, int value) {
     PlanOverride& o = plan_override();

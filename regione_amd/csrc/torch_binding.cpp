@@ -87,16 +87,24 @@ Tensor workspace(int kind, const Tensor& like, size_t bytes) {
             g_ws.splice(g_ws.end(), g_ws, it);                 // most recently used last
             return g_ws.back().buf;
         }
-        same_kind += it->kind == kind;
+        same_kind += (it->kind == kind && it->dev == dev);
     }
-    if (same_kind >= 4)
+    if (same_kind >= 4)          // four lanes per kind AND device (a process driving several GPUs keeps each device's lanes)
         for (auto it = g_ws.begin(); it != g_ws.end(); ++it)
-            if (it->kind == kind) { g_ws.erase(it); break; }
+            if (it->kind == kind && it->dev == dev) { g_ws.erase(it); break; }
     g_ws.push_back({kind, dev, st, at::empty({(int64_t)(bytes / 4)}, like.options().dtype(at::kFloat))});
     return g_ws.back().buf;
 }
 Tensor gemm_ws(const Tensor& like) { return workspace(0, like, rgn_gemm_workspace_bytes()); }
 Tensor attn_ws(const Tensor& like) { return workspace(1, like, rgn_attention_workspace_bytes(0, 0)); }
+
+// the lane of (kind, device of `like`, its current stream) as a tensor: regione_amd.ops borrows it for the block-body GEMMs it launches
+// through ctypes, so that ONE 256 MiB split-K scratch serves a stream whichever way a launch reaches the library (advisor, round 4)
+Tensor workspace_op(const Tensor& like, int64_t kind) {
+    TORCH_CHECK(kind == 0 || kind == 1, "workspace: kind 0 (GEMM split-K) or 1 (attention KV split)");
+    RGN_DEVICE_GUARD(like);
+    return kind == 0 ? gemm_ws(like) : attn_ws(like);
+}
 
 // ---- region ops -------------------------------------------------------------------------------------------------------------
 std::tuple<Tensor, Tensor, Tensor> arp_partition(const Tensor& sample, const OptTensor& model_output, const Tensor& cond,
@@ -371,6 +379,7 @@ TORCH_LIBRARY(regione_mi, m) {
           "Tensor(c!)[] vt_cache, int heads, int[] row_base, float eps=1e-6, int[] fp16_roundtrip=[], int gelu_from_col=-1) -> ()");
     m.def("region_attention(Tensor q, Tensor k_cache, Tensor vt_cache, Tensor(a!) out, int skv, int heads, float scale=-1.0, "
           "float score_bound=0.0) -> ()");
+    m.def("workspace(Tensor like, int kind) -> Tensor");
 }
 
 // CUDA is the dispatch key of HIP tensors in PyTorch-ROCm; no CPU kernels are registered (a CPU tensor fails loudly)
@@ -385,4 +394,5 @@ TORCH_LIBRARY_IMPL(regione_mi, CUDA, m) {
     m.impl("kv_partial_update_pair_", &kv_partial_update_pair_);
     m.impl("kv_partial_update_group_", &kv_partial_update_group_);
     m.impl("region_attention", &region_attention);
+    m.impl("workspace", &workspace_op);
 }

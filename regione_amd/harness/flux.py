@@ -49,6 +49,67 @@ class _Cfg(dict):
         return dict.get(self, k, default)
 
 
+class RowCat:
+    """`torch.cat(parts, dim=1)` of [1, n_i, C] tensors that is never materialised: the pipelines hand `[latents ; image_latents]`
+    (inplace.py:331-332) to the transformer as its pieces, and the x_embedder GEMM - the only reader - takes one problem per piece
+    and writes consecutive row ranges (one group launch, no concat kernel).  `repeat` = a leading batch of identical copies
+    (the B = 2 input of Step1X-Edit's batched CFG, Step1XEdit/inplace.py:381-385).  Quacks like the tensor for what the engine asks
+    of it: shape / size / dtype / device, batch indexing."""
+
+    def __init__(self, parts, repeat: int = 1):
+        self.parts = [p for p in parts if p.shape[1] > 0]
+        assert self.parts and all(p.dim() == 3 and p.shape[0] == 1 and p.shape[2] == self.parts[0].shape[2] for p in self.parts)
+        self.repeat = repeat
+
+    @property
+    def shape(self):
+        return torch.Size((self.repeat, sum(p.shape[1] for p in self.parts), self.parts[0].shape[2]))
+
+    def size(self, i=None):
+        return self.shape if i is None else self.shape[i]
+
+    @property
+    def dtype(self):
+        return self.parts[0].dtype
+
+    @property
+    def device(self):
+        return self.parts[0].device
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            n = len(range(*key.indices(self.repeat)))
+            assert n >= 1
+            return RowCat(self.parts, n)
+        raise TypeError("RowCat supports batch slices only (materialise() for anything else)")
+
+    def materialise(self) -> torch.Tensor:
+        t = ops.cat_rows(self.parts, dim=1)
+        return t if self.repeat == 1 else t.expand(self.repeat, -1, -1)
+
+
+def cat_tokens(transformer, *parts):
+    """The pipelines' `torch.cat([latents, image_latents], dim=1)` (inplace.py:331-332): the never-materialised form for the HIP
+    engine (`accepts_row_cat`), a plain tensor (device-to-device copies) for any other transformer object."""
+    return RowCat(parts) if getattr(transformer, "accepts_row_cat", False) else ops.cat_rows(parts, dim=1)
+
+
+def repeat_batch(x, n: int = 2):
+    """`torch.cat((x,) * n, dim=0)` of a batch-1 input without a copy (the rows are identical: a view / a RowCat repeat)."""
+    return RowCat(x.parts, n) if isinstance(x, RowCat) else x.expand(n, -1, -1)
+
+
+def _x_problems(hidden_states, W, b, dst):
+    """x_embedder problems of ONE image: `hidden_states` [1, M, C] (tensor or RowCat) -> dst [M, d]."""
+    if isinstance(hidden_states, RowCat):
+        out, o = [], 0
+        for p in hidden_states.parts:
+            out.append(ops.Problem(p[0], W, b, dst[o:o + p.shape[1]]))
+            o += p.shape[1]
+        return out
+    return [ops.Problem(hidden_states[0], W, b, dst)]
+
+
 # ---------------------------------------------------------------------------------------------
 # [EXT] scheduler base
 # ---------------------------------------------------------------------------------------------
@@ -222,8 +283,8 @@ class Workspace:
             kw = dict(dtype=torch.bfloat16, device=self.device)
             pad = max(pad, self.skv_pad)
             n = max(branches, len(getattr(self, "k_scratch_b", ())))
-            self.k_scratch_b = [torch.zeros(pad, d, **kw) for _ in range(n)]   # zero-filled: pad rows must stay finite
-            self.vt_scratch_b = [torch.zeros(d, pad, **kw) for _ in range(n)]
+            self.k_scratch_b = [ops.zeros((pad, d), **kw) for _ in range(n)]   # zero-filled: pad rows must stay finite
+            self.vt_scratch_b = [ops.zeros((d, pad), **kw) for _ in range(n)]
             self.k_scratch, self.vt_scratch = self.k_scratch_b[0], self.vt_scratch_b[0]
             self.skv_pad = pad
 
@@ -294,7 +355,9 @@ class Attention:
 
     def _bound_key(self):
         # in-place edits of the adopted norm weights (LoRA merge, .copy_) bump `_version`; a swapped tensor changes data_ptr
-        return tuple((w.data_ptr(), w._version) for w in self._norm_weights())
+        # (inference tensors - weights adopted under torch.inference_mode() - track no version counter and cannot be edited in
+        # place either: keyed on the address alone)
+        return tuple((w.data_ptr(), None if w.is_inference() else w._version) for w in self._norm_weights())
 
     def _amax_pair(self):
         """Device scalars (max|w_q|, max|w_k|) over both streams' norm weights - no host sync."""
@@ -581,6 +644,8 @@ class FluxSingleTransformerBlock:
 class FluxTransformer2DModel:
     """[EXT] module tree of diffusers' FluxTransformer2DModel with HIP-backed blocks."""
 
+    accepts_row_cat = True            # `hidden_states` may arrive as a RowCat (cat_tokens): the x_embedder reads the pieces
+
     def __init__(self, cfg: FluxConfig, device="cuda"):
         self.cfg_model = cfg
         self.config = _Cfg(in_channels=cfg.in_channels, guidance_embeds=cfg.guidance_embeds)
@@ -739,10 +804,10 @@ class FluxTransformer2DModel:
             return t              # Qwen-Image: conditioning = timestep embedding only
         p = mlp("text_embedder", pooled)
         if not self.cfg_model.guidance_embeds or guidance is None:
-            return t + p          # Step1X-Edit: temb = time_embed(t) + vec_embed(y)
+            return ops.add_bf16(t, p, out=t)          # Step1X-Edit: temb = time_embed(t) + vec_embed(y)
         ge = timestep_embedding(guidance.detach().float().cpu()).to(torch.bfloat16).to(self.device)
         g = mlp("guidance_embedder", ge)
-        return (t + g) + p        # two bf16 adds, same order as the module (tiny [1, d] tensors)
+        return ops.add_bf16(ops.add_bf16(t, g, out=t), p, out=t)        # two bf16 adds, same order as the module ([1, d] rows; rgn_add_bf16)
 
     # -- all-step modulation table ----------------------------------------------------------------------
     def precompute_modulations(self, timesteps_div1000: List[torch.Tensor], guidance: torch.Tensor, pooled: torch.Tensor):
@@ -760,7 +825,7 @@ class FluxTransformer2DModel:
                 continue
             keys.append(k)
             rows.append(self.time_text_embed(tsb, gd, pooled))
-        temb = torch.cat(rows, 0).contiguous()                       # [S, d] bf16
+        temb = ops.cat_rows(rows, dim=0)                             # [S, d] bf16 (device-to-device copies)
         table = torch.empty(temb.shape[0], self.mod_total, dtype=torch.bfloat16, device=self.device)
         ops.gemm(ops.silu(temb), self.mod_w, self.mod_b, table)
         if not hasattr(self, "_mod_tables") or len(self._mod_tables) > 4:
@@ -864,7 +929,7 @@ class FluxTransformer2DModel:
         ws = self._ws_for_stream()
         ws.ensure(R, R)
         d = self.cfg_model.d
-        ops.gemm(hidden_states[0], self.x_embedder_weight, self.x_embedder_bias, ws.x[T:R])
+        ops.gemm_group(_x_problems(hidden_states, self.x_embedder_weight, self.x_embedder_bias, ws.x[T:R]))
         enc = encoder_hidden_states[0]
         if self.cfg_model.txt_norm:
             enc = ops.rms_norm_rows(enc, self.txt_norm_weight)
@@ -936,7 +1001,7 @@ def _run_multi(self, recs):
         hidden, enc_hs, pooled, timestep, guidance, rope, _, jkw = r["args"]
         out_rows = r["out_rows"] if SKIP_UNREAD_ROWS else None
         Mo = M if out_rows is None else min(int(out_rows), M)
-        emb_x.append(ops.Problem(hidden[0], self.x_embedder_weight, self.x_embedder_bias, v.x[T:T + M]))
+        emb_x.append(_x_problems(hidden, self.x_embedder_weight, self.x_embedder_bias, v.x[T:T + M]))
         enc = enc_hs[0]
         if self.cfg_model.txt_norm:
             enc = ops.rms_norm_rows(enc, self.txt_norm_weight)
@@ -949,7 +1014,12 @@ def _run_multi(self, recs):
             mods = Modulation(ops.gemv(temb, self.mod_w, self.mod_b, silu_input=True), d)
         ctxs.append(FwdCtx(v, T, M, mods, tag=(jkw or {}).get("tag"), out_rows=Mo if SKIP_UNREAD_ROWS else None))
         ropes.append(rope)
-    ops.gemm_group(emb_x)
+    flat = [p for ps in emb_x for p in ps]
+    if len(flat) <= 4:
+        ops.gemm_group(flat)                  # [latents ; image_latents] x two branches: four problems, one launch
+    else:
+        for ps in emb_x:
+            ops.gemm_group(ps)
     ops.gemm_group(emb_c)
     blocks = list(self.transformer_blocks) + list(self.single_transformer_blocks)
     for block in blocks[:-1]:
@@ -1065,7 +1135,7 @@ class FluxKontextPipeline:
         self._precompute(timesteps, guidance, latents.dtype, pooled_prompt_embeds,
                          negative_pooled_prompt_embeds if do_true_cfg else None)
         for i, t in enumerate(timesteps):
-            x = torch.cat([latents, image_latents], dim=1)
+            x = cat_tokens(self.transformer, latents, image_latents)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             def branch(embeds, pooled_e):
                 self.transformer.out_rows_hint = latents.size(1)

@@ -140,7 +140,7 @@ class QwenImageEditPipeline(H.FluxKontextPipeline):
         self._precompute(timesteps, None, latents.dtype)
         tr = self.transformer
         for i, t in enumerate(timesteps):
-            x = torch.cat([latents, image_latents], dim=1)
+            x = H.cat_tokens(self.transformer, latents, image_latents)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             def branch(embeds, tag):
                 tr.out_rows_hint = latents.size(1)

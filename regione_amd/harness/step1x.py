@@ -78,7 +78,7 @@ class Step1XEditTransformer2DModel(H.FluxTransformer2DModel):
         if batched:
             res = self.end_batch()
             outs = [h.resolve(res) for h in outs]
-        out = torch.cat(outs, 0)
+        out = outs[0] if len(outs) == 1 else ops.cat_rows(outs, dim=0)
         return (out,) if not return_dict else H._Cfg(sample=out)
 
 
@@ -98,7 +98,12 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
         return TO.R.cfg_combine(pos.contiguous(), neg.contiguous(), true_cfg_scale, mode, process_norm_power)
 
     def _batched_inputs(self, x, prompt_embeds, negative_prompt_embeds):
-        return torch.cat((x, x), dim=0), torch.cat((prompt_embeds, negative_prompt_embeds), dim=0)
+        """The B = 2 inputs of the reference's batched CFG (Step1XEdit/inplace.py:381-385): `cat((x, x))` as a copy-free repeat, the
+        two prompt embeddings stacked once per (cond, uncond) pair of tensors (device-to-device copies, not once per step)."""
+        key = (prompt_embeds.data_ptr(), negative_prompt_embeds.data_ptr(), prompt_embeds._version, negative_prompt_embeds._version)
+        if getattr(self, "_pe_key", None) != key:
+            self._pe_key, self._pe = key, ops.cat_rows((prompt_embeds, negative_prompt_embeds), dim=0)
+        return H.repeat_batch(x, 2), self._pe
 
     @torch.no_grad()
     def __call__(self, image=None, prompt_embeds=None, pooled_prompt_embeds=None, negative_prompt_embeds=None,
@@ -115,7 +120,7 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
             tr.set_vec((pooled_prompt_embeds, negative_pooled_prompt_embeds))
         self._precompute(timesteps, None, latents.dtype, pooled_prompt_embeds, negative_pooled_prompt_embeds)
         for i, t in enumerate(timesteps):
-            x, pe = self._batched_inputs(torch.cat([latents, image_latents], dim=1), prompt_embeds, negative_prompt_embeds)
+            x, pe = self._batched_inputs(H.cat_tokens(self.transformer, latents, image_latents), prompt_embeds, negative_prompt_embeds)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             timestep = torch.cat((timestep, timestep), dim=0)
             tr.out_rows_hint = latents.size(1)
@@ -149,7 +154,7 @@ class Step1XEditPipelineV1P2(Step1XEditPipeline):
         tr = self.transformer
         self._precompute(timesteps, None, latents.dtype, pooled_prompt_embeds, negative_pooled_prompt_embeds)
         for i, t in enumerate(timesteps):
-            x = torch.cat([latents, image_latents], dim=1)
+            x = H.cat_tokens(self.transformer, latents, image_latents)
             timestep = t.expand(latents.shape[0]).to(latents.dtype)
             def branch(pe, y, ids_t, tag):
                 rope = tr.pos_embed(torch.cat((ids_t, latent_ids), dim=0), tr.device)

@@ -157,6 +157,20 @@ _gemm_ws = {}
 MAX_WS_LANES = 4          # scratch lanes kept per kind (device x stream), least recently used dropped
 
 
+def _shared_lane(device, kind: int):
+    """With the C++ registration active its lane table is the one provider (torch.ops.regione_mi.workspace): the block-body GEMMs
+    launched from here share the buffer the fused projections use on the same stream.  None -> the Python table below."""
+    import sys
+    to = sys.modules.get("regione_amd.torch_ops")
+    if to is None or getattr(to, "REGISTRATION", "py") != "cpp":
+        return None
+    probes = _shared_lane.__dict__.setdefault("probes", {})
+    like = probes.get(str(device))
+    if like is None:
+        like = probes[str(device)] = torch.empty(0, dtype=torch.float32, device=device)
+    return torch.ops.regione_mi.workspace(like, kind)
+
+
 def _ws_lane(table: dict, device, make):
     """One scratch buffer per (device, stream), bounded LRU: two forwards running on two streams must not share split-K /
     KV-split partials, and a host calling from many short-lived streams must not pin 256 + 128 MiB per stream forever.  A
@@ -165,8 +179,9 @@ def _ws_lane(table: dict, device, make):
     key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     buf = table.pop(key, None)
     if buf is None:
-        while len(table) >= MAX_WS_LANES:
-            table.pop(next(iter(table)))
+        mine = [k for k in table if k[0] == key[0]]           # the bound is per device
+        while len(mine) >= MAX_WS_LANES:
+            table.pop(mine.pop(0))
         buf = make()
     table[key] = buf                     # most recently used last
     return buf
@@ -174,6 +189,9 @@ def _ws_lane(table: dict, device, make):
 
 def gemm_workspace(device) -> torch.Tensor:
     """fp32 scratch for the round-aware GEMM schedule (one per device and stream, see _ws_lane)."""
+    shared = _shared_lane(device, 0)
+    if shared is not None:
+        return shared
     return _ws_lane(_gemm_ws, device,
                     lambda: torch.empty(_lib.lib().rgn_gemm_workspace_bytes() // 4, dtype=torch.float32, device=device))
 
@@ -396,6 +414,49 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def add_bf16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 a + b (one rounding, like torch) into `out` (default: a new tensor; may alias an input)."""
+    assert a.dtype == b.dtype == torch.bfloat16 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    assert out.dtype == torch.bfloat16 and out.numel() == a.numel() and out.is_contiguous()
+    _lib.check(_lib.lib().rgn_add_bf16(_p(a), _p(b), _p(out), a.numel(), _stream()), "rgn_add_bf16")
+    return out
+
+
+def sel_rows(edited_ids: torch.Tensor, T: int) -> torch.Tensor:
+    """int64 [T + K]: [0..T) then T + edited_ids - the cache rows of a region step (inplace.py:732-733)."""
+    idv = edited_ids.reshape(-1)
+    assert idv.dtype == torch.int64 and idv.is_contiguous()
+    out = torch.empty(T + idv.numel(), dtype=torch.int64, device=idv.device)
+    _lib.check(_lib.lib().rgn_sel_rows(_p(idv), idv.numel(), int(T), _p(out), _stream()), "rgn_sel_rows")
+    return out
+
+
+def zeros(shape, dtype=torch.bfloat16, device="cuda") -> torch.Tensor:
+    """torch.empty + hipMemsetAsync on the current stream (no fill kernel)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    _lib.check(_lib.lib().rgn_fill_zero(_p(t), t.numel() * t.element_size(), _stream()), "rgn_fill_zero")
+    return t
+
+
+def cat_rows(parts, dim: int = 1) -> torch.Tensor:
+    """torch.cat of contiguous pieces along `dim` when every piece is one contiguous run of the result (dim 0, or dim 1 of
+    batch-1 tensors): device-to-device copies (hipMemcpyAsync), no concat kernel."""
+    parts = list(parts)
+    ref = parts[0]
+    assert all(p.is_contiguous() and p.dtype == ref.dtype for p in parts) and (dim == 0 or all(p.shape[0] == 1 for p in parts))
+    shape = list(ref.shape)
+    shape[dim] = sum(p.shape[dim] for p in parts)
+    out = torch.empty(shape, dtype=ref.dtype, device=ref.device)
+    o = 0
+    for p in parts:
+        n = p.shape[dim]
+        out.narrow(dim, o, n).copy_(p)
+        o += n
+    return out
+
+
 def ln_modulate(x: torch.Tensor, out: torch.Tensor, shift1, scale1, split_row: int = 0, shift0=None, scale0=None,
                 eps: float = 1e-6) -> torch.Tensor:
     M, d = x.shape
@@ -439,6 +500,9 @@ _attn_ws = {}
 
 def attention_workspace(device) -> torch.Tensor:
     """fp32 scratch for the round-aware attention schedule (allocated once per device and stream)."""
+    shared = _shared_lane(device, 1)
+    if shared is not None:
+        return shared
     return _ws_lane(_attn_ws, device,
                     lambda: torch.empty(_lib.lib().rgn_attention_workspace_bytes(0, 0) // 4, dtype=torch.float32, device=device))
 

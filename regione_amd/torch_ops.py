@@ -204,6 +204,16 @@ _define("region_attention",
         _region_attention, lambda *a, **k: None)
 
 
+def _workspace(like, kind):
+    return ops.gemm_workspace(like.device) if kind == 0 else ops.attention_workspace(like.device)
+
+
+# the scratch lane (kind 0 = GEMM split-K partials, 1 = attention KV-split partials) of `like`'s device and current stream: ONE
+# provider for both ways a launch reaches the library (C++ ops and the ctypes wrappers)
+_define("workspace", "(Tensor like, int kind) -> Tensor", _workspace,
+        lambda like, kind: like.new_empty((1,), dtype=torch.float32))
+
+
 def registered() -> Tuple[str, ...]:
     return tuple(sorted(_defined))
 

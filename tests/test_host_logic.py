@@ -46,6 +46,8 @@ def cpu_ops(monkeypatch):
         gather_rows=lambda x, ids: O.ids_gather(x, ids) if x.dim() == 3 else x[ids.reshape(-1)],
         scatter_rows_=lambda s, ids, d: O.ids_scatter(s, ids, d)))
     monkeypatch.setattr(fk, "ids_gather", lambda x, ids, *a, **k: O.ids_gather(x, ids))
+    # `selection` of inplace.py:732-733 (rgn_sel_rows on the device)
+    monkeypatch.setattr(ops, "sel_rows", lambda ids, T: torch.cat((torch.arange(T), ids.reshape(-1) + T)))
 
 
 class FakeTransformer:

@@ -65,13 +65,13 @@ def test_cpp_library_alone_defines_the_ops_with_the_python_registrations_schemas
                        env=dict(os.environ, RGN_TORCH_OPS="py"))
     assert r.returncode == 0, r.stderr[-3000:]
     py = json.loads(r.stdout.strip().splitlines()[-1])
-    assert cpp == py and len(cpp) == 10
+    assert cpp == py and len(cpp) == 11
 
 
 def test_ops_are_registered_with_schemas():
     assert set(T.registered()) == {"arp_partition", "gather_rows", "scatter_rows_", "split_euler_step", "avd_apply",
                                    "cfg_combine", "kv_partial_update_", "kv_partial_update_pair_", "kv_partial_update_group_",
-                                   "region_attention"}
+                                   "region_attention", "workspace"}
     s = str(torch.ops.regione_mi.scatter_rows_.default._schema)
     assert "Tensor(a!) dst" in s
     s = str(torch.ops.regione_mi.kv_partial_update_.default._schema)
