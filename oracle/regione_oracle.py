@@ -685,6 +685,8 @@ def denoise(model_fn, st: RegionState, latents, image_latents, latent_ids, txt_l
             noise_pred = model_fn(x, timesteps[i], ids)[:, :latents.size(1)]          # :336-347
             if neg_model_fn is not None and true_cfg_scale > 1:                       # true CFG, :349-364
                 neg = neg_model_fn(x, timesteps[i], ids)[:, :latents.size(1)]
+                if trace is not None:                                                 # the two branch velocities before the combine
+                    trace.setdefault("branches", {})[i] = (noise_pred.clone(), neg.clone())
                 noise_pred = cfg_combine(family, noise_pred, neg, true_cfg_scale, timesteps[i])
             cache = noise_pred                                                        # :365
         if trace is not None:

@@ -119,6 +119,8 @@ class RegionEQwenImageEditPipeline(HQ.QwenImageEditPipeline):
                                                          lambda: branch(prompt_embeds, "cond"),
                                                          lambda: branch(negative_prompt_embeds, "uncond"), concurrent=conc,
                                                          batch_on=tr)
+                    if trace is not None:            # the two branch velocities before the combine (parity attribution tools)
+                        trace.setdefault("branches", {})[i] = (noise_pred.clone(), neg.clone())
                     noise_pred = TO.R.cfg_combine(noise_pred, neg, true_cfg_scale, ops.CFG_QWEN_NORM)
                 else:
                     noise_pred = branch(prompt_embeds, "cond")

@@ -43,14 +43,18 @@ def test_full_depth_trunk_28_steps_vs_oracle_denoise(family):
     a norm-preserving CFG combine `neg + 4 (pos - neg)` put the oracle's own re-ordered run 39.9 dB from itself, so the bar for
     that family is "no further from the oracle than 2 dB below the oracle's own spread" AND >= 38 dB absolute; round 5 attributes
     the gap per branch (profiles/r05_parity_qwen_branches.json: both branch velocities >= 40 dB, the combine amplifies)."""
+    import json
     import parity_full_depth as P
-    r = P.narrow_loop(family, alt=(family == "qwen"))
+    r = P.narrow_loop(family, alt=False)
     assert r["blocks"] == (60 if family == "qwen" else 57)
     assert r["hip_plan"] == r["oracle_plan"] and "R" in r["hip_plan"] and "C" in r["hip_plan"]
     assert r["ids_bit_exact"] and 0 < r["hip_K_e"] < 256
     if family == "qwen":
-        assert r["oracle_reordered_ids_equal"]
-        spread = r["psnr_oracle_reordered_vs_oracle_db"]
+        # the oracle's own spread (its reversed-K run vs its plain run) for this exact case is a property of the ORACLE: measured once
+        # by the tool (`python tools/parity_full_depth.py --cases qwen_loop`, a second 11 s oracle pass) and read from the committed report
+        rep = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_full_depth.json")))
+        spread = next(c for c in rep["cases"] if c["case"] == "qwen_narrow_28_steps")["psnr_oracle_reordered_vs_oracle_db"]
+        assert 39.0 <= spread <= 41.0
         assert r["psnr_final_db"] >= 38.0 and r["psnr_final_db"] >= spread - 2.0, (r["psnr_final_db"], spread)
     else:
         assert r["psnr_final_db"] >= 40.0, r["psnr_final_db"]

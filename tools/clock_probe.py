@@ -7,11 +7,17 @@ import torch
 from regione_amd import ops
 
 
+MEMACT = []          # "GPU Memory Read/Write Activity (%)" = the memory controllers' (UMC) busy share: the one HBM-side reading this image offers
+
+
 def smi():
-    out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True).stdout
+    out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmemuse"], capture_output=True, text=True).stdout
     sclk = re.search(r"sclk clock level.*?\((\d+)Mhz\)", out)
     mclk = re.search(r"mclk clock level.*?\((\d+)Mhz\)", out)
     pw = re.search(r"Power \(W\):\s*([\d.]+)", out)
+    ma = re.search(r"Memory Read/Write Activity \(%\):\s*([\d.]+)", out)
+    if ma:
+        MEMACT.append(float(ma.group(1)))
     return (sclk and sclk.group(1), mclk and mclk.group(1), pw and pw.group(1))
 
 
@@ -55,7 +61,9 @@ def summarise(what, samples, us_per_launch, flops_per_launch):
     ws = [float(p) for _, _, p in samples if p]
     cl = [float(c) for c, _, _ in samples if c]
     ws, cl = ws[len(ws) // 5:], cl[len(cl) // 5:]                  # drop the ramp
-    rec = dict(kernel=what, samples=len(ws), power_w_mean=sum(ws) / max(len(ws), 1), power_w_max=max(ws, default=0.0),
+    ma = MEMACT[len(MEMACT) // 5:]
+    rec = dict(kernel=what, samples=len(ws), hbm_controller_activity_pct_mean=(sum(ma) / len(ma)) if ma else None,
+               hbm_controller_activity_pct_max=max(ma, default=None), power_w_mean=sum(ws) / max(len(ws), 1), power_w_max=max(ws, default=0.0),
                sclk_mhz_mean=sum(cl) / max(len(cl), 1), sclk_mhz_min=min(cl, default=0.0), us_per_launch=us_per_launch)
     if flops_per_launch and us_per_launch:
         tf = flops_per_launch / us_per_launch / 1e6
@@ -87,6 +95,11 @@ def main():
         A, W, b = rnd(8704, 3072), rnd(21504, 3072) * 0.05, rnd(21504)
         out = torch.empty(8704, 21504, dtype=torch.bfloat16, device="cuda")
         fn, n = (lambda: ops.gemm(A, W, b, out)), 2000
+    elif what == "gemv":            # an HBM-streaming yardstick for the memory-activity column: the all-layer AdaLN GEMV, 6.5 GB of weights per launch
+        N, K = 1056768, 3072
+        W, b, x = rnd(N, K), rnd(N), rnd(1, K)
+        fn, n = (lambda: ops.gemv(x, W, b, silu_input=True)), 1500
+        FLOPS_OVERRIDE[what] = 2.0 * N * K
     elif what == "vendor":          # reference point: the vendor library's kernel on the same shape (hipBLASLt via torch.addmm)
         A, W, b = rnd(8704, 3072), rnd(21504, 3072) * 0.05, rnd(21504)
         out = torch.empty(8704, 21504, dtype=torch.bfloat16, device="cuda")

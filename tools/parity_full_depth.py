@@ -316,33 +316,39 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
 NARROW = dict(heads=4, head_dim=128, joint_dim=512, pooled_dim=64)
 
 
-def narrow_loop(family="flux", grid=16, T=32, device="cuda", hip=True, alt=True):
+def narrow_loop(family="flux", grid=16, T=32, device="cuda", hip=True, alt=True, width="narrow"):
+    """width = "narrow": d = 512 (4 heads); "full": the trunk's real width (d = 3072, 24 heads) - the whole 28-step loop at full width
+    AND depth (round 5; ~1-2 min of CPU oracle per pass for FLUX, twice that for Qwen's two branches)."""
     t_start = time.time()
     # d = 512 matmuls on 544 rows: a 256-thread pool costs more in fork / join than the arithmetic (MI355X host: 320 s for the
-    # Qwen case against 21 s on 8 threads)
+    # Qwen case against 21 s on 8 threads); at full width the matmuls are 36 x larger: 64 threads
     threads = torch.get_num_threads()
-    torch.set_num_threads(min(threads, 16))
+    torch.set_num_threads(min(threads, 16 if width == "narrow" else 64))
     try:
-        return _narrow_loop(family, grid, T, device, hip, alt, t_start)
+        return _narrow_loop(family, grid, T, device, hip, alt, t_start, width)
     finally:
         torch.set_num_threads(threads)
 
 
-def _narrow_loop(family, grid, T, device, hip, alt, t_start):
+def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
     h = w = grid
     L = h * w
     qwen, s1x = family == "qwen", family == "step1x_v1p2"
+    dims = NARROW if width == "narrow" else dict(heads=24, head_dim=128, joint_dim=4096, pooled_dim=768)
     if qwen:
-        cfg = synth.FluxConfig(**dict(synth.QWEN, **dict(NARROW, pooled_dim=768)))
+        cfg = synth.FluxConfig(**(dict(synth.QWEN, **dict(NARROW, pooled_dim=768)) if width == "narrow" else dict(synth.QWEN)))
         Tn, scale, thr_cache, fam = 24, 4.0, 0.03, "qwen"
     elif s1x:           # Step1X-Edit v1p2: the FLUX trunk without a guidance embedder, sequential tagged CFG, one K/V cache per tag,
-        cfg = synth.FluxConfig(guidance_embeds=False, **NARROW)        # text lengths 32 / 24 (Step1XEditV1P2/inplace.py:398,416,833,868)
+        cfg = synth.FluxConfig(guidance_embeds=False, **dims)        # text lengths 32 / 24 (Step1XEditV1P2/inplace.py:398,416,833,868)
         Tn, scale, thr_cache, fam = 24, 4.0, 0.02, "step1x_v1p2"
     else:
-        cfg = synth.FluxConfig(**NARROW)
+        cfg = synth.FluxConfig(**dims)
         Tn, scale, thr_cache, fam = None, 1.0, 0.04, "flux"
     w_std = cfg.d ** -0.5
-    wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=w_std)
+    if width == "narrow":
+        wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=w_std)
+    else:               # 12-20 B parameters: drawn on the device (seconds), copied to the host for the oracle
+        wts_dev, wts = _gpu_weights(cfg, seed=42, w_std=w_std)
     lat, img0, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=42, dtype=torch.bfloat16)
     if qwen or s1x:
         _, _, nprompt, npooled = synth.make_edit_inputs(h, w, Tn, cfg, seed=43, dtype=torch.bfloat16)
@@ -350,7 +356,7 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
         ocfg = O.FluxCfg(n_double=cfg.n_double, n_single=0, heads=cfg.heads, head_dim=cfg.head_dim, joint_dim=cfg.joint_dim)
         ids_full = torch.arange(2 * L)
     else:
-        ocfg = O.FluxCfg(n_double=cfg.n_double, n_single=cfg.n_single, **NARROW)
+        ocfg = O.FluxCfg(n_double=cfg.n_double, n_single=cfg.n_single, **dims)
         ids_full = synth.flux_latent_ids(h, w)
     threshold = 0.5
 
@@ -393,7 +399,7 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
     tr_o = {}
     ref, st = oracle_run(img, tr_o)
     t_oracle = time.time() - t0
-    res = dict(case=f"{family}_narrow_28_steps", family=family, blocks=cfg.n_layers, d=cfg.d, grid=[h, w], T=T,
+    res = dict(case=f"{family}_{width}_28_steps", family=family, blocks=cfg.n_layers, d=cfg.d, grid=[h, w], T=T,
                oracle_plan="".join(tr_o["kind"]), oracle_K_e=int(st.edited_ids.shape[1]), oracle_s=round(t_oracle, 1))
     if alt:                                 # the reference arithmetic under another summation order: its own spread
         tr_a = {}
@@ -407,15 +413,19 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
     if not hip:
         return res
     from regione_amd import RegionEHelper
+    src = wts if width == "narrow" else wts_dev
     if qwen:
         from regione_amd.harness import qwen as HQ
-        pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, device).load_state_dict(wts))
+        pipe = HQ.QwenImageEditPipeline(HQ.QwenImageTransformer2DModel(cfg, device).load_state_dict_stream(iter(src.items())))
     elif s1x:
         from regione_amd.harness import step1x as HS
-        pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, device).load_state_dict(wts))
+        pipe = HS.Step1XEditPipelineV1P2(HS.Step1XEditTransformer2DModel(cfg, device).load_state_dict_stream(iter(src.items())))
     else:
         from regione_amd.harness import flux as H
-        pipe = H.FluxKontextPipeline(H.FluxTransformer2DModel(cfg, device).load_state_dict(wts))
+        pipe = H.FluxKontextPipeline(H.FluxTransformer2DModel(cfg, device).load_state_dict_stream(iter(src.items())))
+    if width != "narrow":
+        del wts_dev, src
+        torch.cuda.empty_cache()
     helper = RegionEHelper(pipe)
     helper.set_params(threshold=threshold)
     helper.enable()
@@ -437,6 +447,24 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
     res.update(hip_plan="".join(tr_h["kind"]), ids_bit_exact=ids_equal, hip_K_e=int(Mg.edited_ids.shape[1]),
                psnr_final_db=round(O.psnr(out, ref), 2), rel_final=rel(out, ref), psnr_per_step_db=per_step,
                wall_s=round(time.time() - t_start, 1))
+    if "branches" in tr_h and "branches" in tr_o:
+        # attribution of the combined velocity's distance: each branch's velocity against the oracle's at
+        # every computed step, next to the combined one - the CFG combine `neg + s (pos - neg)` (norm-preserving for Qwen) multiplies
+        # the two branches' (independent) differences by ~sqrt(s^2 + (s - 1)^2): 5 x = 14 dB at s = 4
+        br = []
+        for i in sorted(set(tr_h["branches"]) & set(tr_o["branches"])):
+            (ph, nh), (po, no) = tr_h["branches"][i], tr_o["branches"][i]
+            if ph.shape != po.shape:
+                continue
+            br.append(dict(step=i, kind=tr_h["kind"][i], psnr_cond_db=round(O.psnr(ph.cpu(), po), 2), psnr_uncond_db=round(O.psnr(nh.cpu(), no), 2),
+                           psnr_combined_db=round(O.psnr(tr_h["noise_pred"][i].cpu(), tr_o["noise_pred"][i]), 2),
+                           psnr_input_latents_db=(round(O.psnr(tr_h["latents"][i - 1].cpu(), tr_o["latents"][i - 1]), 2) if i else None)))
+        worst = min(br, key=lambda r: r["psnr_combined_db"]) if br else None
+        res.update(branch_velocities_per_step=br, worst_combined_step=worst, cfg_scale=scale,
+                   cfg_amplification_expected_db=round(20 * __import__("math").log10((scale ** 2 + (scale - 1) ** 2) ** 0.5), 1))
+        if worst:
+            print(f"[full-depth parity] {family}: worst combined velocity at step {worst['step']} ({worst['kind']}): combined "
+                  f"{worst['psnr_combined_db']} dB, cond {worst['psnr_cond_db']} dB, uncond {worst['psnr_uncond_db']} dB", flush=True)
     print(f"[full-depth parity] {family} {cfg.n_layers} blocks d={cfg.d}, 28 steps: plan {res['hip_plan']} "
           f"({'==' if res['hip_plan'] == res['oracle_plan'] else '!='} oracle), K_e {res['hip_K_e']} ids "
           f"{'bit-exact' if ids_equal else 'DIFFER'}, final latents {res['psnr_final_db']:.1f} dB "
@@ -446,15 +474,29 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity_full_depth.json"))
-    ap.add_argument("--cases", default="flux_loop,qwen_loop,step1x_v1p2_loop,flux_width,qwen_width")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity_full_depth.json"))
+    ap.add_argument("--cases", default="flux_loop,qwen_loop,step1x_v1p2_loop,flux_width,qwen_width",
+                    help="<family>_loop (d = 512, 28 steps) | <family>_fullloop (d = 3072, 28 steps, 16 x 16 grid) | <family>_width (d = 3072, "
+                         "16 x 16 grid, one FULL + one REGION step) | <family>_headline (d = 3072, 64 x 64 grid, T = 512, K_e = 1024: the "
+                         "bench's shape, one FULL + one REGION step; ~10 min of CPU oracle)")
     ap.add_argument("--no-truth", action="store_true", help="skip the fp32 oracle run of the full-width cases")
     ap.add_argument("--no-alt", action="store_true", help="skip the reversed-K oracle run of the full-width cases")
     ns = ap.parse_args()
     report = dict(host_threads=torch.get_num_threads(), cases=[])
     for c in ns.cases.split(","):
         fam, kind = c.rsplit("_", 1)
-        report["cases"].append(narrow_loop(fam) if kind == "loop" else full_width(fam, truth=not ns.no_truth, alt=not ns.no_alt))
+        if kind == "loop":
+            r = narrow_loop(fam)
+        elif kind == "fullloop":
+            r = narrow_loop(fam, width="full")
+        elif kind == "headline":
+            r = full_width(fam, grid=64, T=512, truth=False, alt=False)
+            r["case"] = f"{fam}_headline_shape"
+        else:
+            r = full_width(fam, truth=not ns.no_truth, alt=not ns.no_alt)
+        report["cases"].append(r)
+        with open(ns.out, "w") as f:                       # after every case: a long run cut short keeps what it finished
+            json.dump(report, f, indent=1)
     os.makedirs(os.path.dirname(ns.out), exist_ok=True)
     with open(ns.out, "w") as f:
         json.dump(report, f, indent=1)
