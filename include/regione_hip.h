@@ -42,8 +42,7 @@ size_t rgn_abi_struct_bytes(void);
 const char* rgn_last_error(void);
 /* Launch-plan override: the library's one test / measurement hook (no reference counterpart).  Every knob is -1 (= the launch cost
  * models decide) in a shipped run.  `key` in {gemm_pieces (1 = one plain launch, n >= 2 = n K pieces of a round's remainder),
- * gemm_geometry (128 | 256), gemm_asm (0 = compiler-scheduled kernels only), gemm_quarter (0 never | 1 always), gemm_persistent (0 = one
- * workgroup per tile instead of the persistent tile loop), attn_waves (4 | 8),
+ * gemm_geometry (128 | 256), gemm_asm (0 = compiler-scheduled kernels only), gemm_quarter (0 never | 1 always), attn_waves (4 | 8),
  * attn_split (0 = never cut KV), attn_streamk (0 = equal pieces only | 1 = wherever possible), attn_asm (0 = compiler-scheduled
  * loop)}; value -1 restores the default; key NULL resets every knob.  Process-wide, not synchronised with launches in flight on other
  * threads.  The same knobs can be preset once per process with RGN_PLAN_OVERRIDE="key=value,key=value" - the only environment

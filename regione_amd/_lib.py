@@ -140,7 +140,7 @@ def lib():
 
 import contextlib as _contextlib
 
-PLAN_KEYS = ("gemm_pieces", "gemm_geometry", "gemm_asm", "gemm_quarter", "gemm_persistent", "attn_waves", "attn_split", "attn_streamk", "attn_asm")
+PLAN_KEYS = ("gemm_pieces", "gemm_geometry", "gemm_asm", "gemm_quarter", "attn_waves", "attn_split", "attn_streamk", "attn_asm")
 
 
 @_contextlib.contextmanager

@@ -52,7 +52,6 @@ struct PlanOverride {
     int gemm_geometry;    // 128 | 256: tile geometry
     int gemm_asm;         // 0 = compiler-scheduled kernels only (the fallback of operands >= 4 GiB / K < 128 / short fp8 K)
     int gemm_quarter;     // 0 = never, 1 = the remainder always as quarter tiles on the 128 geometry
-    int gemm_persistent;  // 0 = one workgroup per tile instead of the persistent tile loop of the hand-scheduled whole-K launches
     int attn_waves;       // 4 | 8 waves per workgroup
     int attn_split;       // 0 = never cut the KV range of remainder items
     int attn_streamk;     // 0 = equal KV pieces only, 1 = stream-K wherever it is possible

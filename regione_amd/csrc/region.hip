@@ -323,7 +323,7 @@ __global__ void sel_rows_kernel(const int64_t* __restrict__ ids, int K, int T, i
 static bool plan_set(PlanOverride& o, const char* key, int value) {
     struct { const char* name; int* field; } tab[] = {
         {"gemm_pieces", &o.gemm_pieces}, {"gemm_geometry", &o.gemm_geometry}, {"gemm_asm", &o.gemm_asm}, {"gemm_quarter", &o.gemm_quarter},
-        {"gemm_persistent", &o.gemm_persistent}, {"attn_waves", &o.attn_waves}, {"attn_split", &o.attn_split}, {"attn_streamk", &o.attn_streamk}, {"attn_asm", &o.attn_asm}};
+        {"attn_waves", &o.attn_waves}, {"attn_split", &o.attn_split}, {"attn_streamk", &o.attn_streamk}, {"attn_asm", &o.attn_asm}};
     for (auto& t : tab)
         if (strcmp(t.name, key) == 0) { *t.field = value; return true; }
     return false;
@@ -331,7 +331,7 @@ static bool plan_set(PlanOverride& o, const char* key, int value) {
 
 PlanOverride& plan_override() {
     static PlanOverride o = [] {
-        PlanOverride v{-1, -1, -1, -1, -1, -1, -1, -1, -1};
+        PlanOverride v{-1, -1, -1, -1, -1, -1, -1, -1};
         const char* e = getenv("RGN_PLAN_OVERRIDE");
         if (e != nullptr) {
             char buf[256];
@@ -373,7 +373,7 @@ int rgn_fill_zero(void* ptr, size_t bytes, void* stream) {
 
 int rgn_plan_override(const char* key, int value) {
     PlanOverride& o = plan_override();
-    if (key == nullptr) { o = PlanOverride{-1, -1, -1, -1, -1, -1, -1, -1, -1}; return 0; }
+    if (key == nullptr) { o = PlanOverride{-1, -1, -1, -1, -1, -1, -1, -1}; return 0; }
     return plan_set(o, key, value) ? 0 : fail(RGN_E_BADARG, "plan_override: unknown key");
 }
 const char* rgn_last_error(void) { return g_err; }
