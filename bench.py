@@ -635,20 +635,28 @@ def main():
             "value": O.psnr(out.cpu(), van.cpu()),
             "note": "random weights: not the quality metric (needs a real checkpoint; unmeasurable in this image)"}
     if rank == 0 and world == 1:
-        # parity at the trunks' real depth (tools/parity_full_depth.py, tests/test_gpu_full_depth.py): the committed report
-        pf = os.path.join(ROOT, "profiles", "r04_parity_full_depth.json")
-        if os.path.exists(pf):
-            cases = {c["case"]: c for c in json.load(open(pf))["cases"]}
-            par = {"source": "profiles/r04_parity_full_depth.json (MI355X; hip vs oracle torch-CPU bf16)"}
-            for name, c in cases.items():
+        # parity with the oracle (torch-CPU bf16 = the reference's dtype path), committed tool reports (tools/parity_full_depth.py; the
+        # -m gpu suite re-runs the 16 x 16-grid cases with assertions): round 5 = the HEADLINE shape itself (L = 4096, T = 512, K_e = 1024,
+        # 57 blocks, d = 3072: one FULL step with store + one REGION step) and the 28-step loops at full width AND depth; round 4 = the
+        # d = 512 loops and the 16 x 16-grid full-width steps
+        par = {"sources": [f for f in PARITY_FILES + ("profiles/r04_parity_full_depth.json",) if os.path.exists(os.path.join(ROOT, f))]}
+        for f in par["sources"]:
+            for c in json.load(open(os.path.join(ROOT, f)))["cases"]:
+                name = c["case"]
                 if "rows" in c:
                     par[name] = {"min_psnr_db": min(r["psnr_hip_vs_oracle_db"] for r in c["rows"]), "blocks": c["blocks"], "d": c["d"],
+                                 "grid": c.get("grid"), "T": c.get("T"), "K_e": c.get("K_e"),
+                                 "untouched_cache_rows_bit_identical": c.get("untouched_rows_bit_identical"),
                                  "oracle_own_spread_min_psnr_db": min((r["psnr_oracle_reordered_vs_oracle_db"] for r in c["rows"]
                                                                        if "psnr_oracle_reordered_vs_oracle_db" in r), default=None)}
                 else:
                     par[name] = {"final_latents_psnr_db": c.get("psnr_final_db"), "ids_bit_exact": c.get("ids_bit_exact"),
-                                 "blocks": c["blocks"], "d": c["d"],
+                                 "plan_equal": c.get("hip_plan") == c.get("oracle_plan"), "blocks": c["blocks"], "d": c["d"],
                                  "oracle_own_spread_psnr_db": c.get("psnr_oracle_reordered_vs_oracle_db")}
+                    w = c.get("worst_combined_step")
+                    if w:          # true-CFG families: where the combined velocity's distance comes from (per-branch vs combine)
+                        par[name]["worst_step_branch_attribution_db"] = {k: w[k] for k in ("step", "psnr_cond_db", "psnr_uncond_db", "psnr_combined_db")}
+        if len(par) > 1:
             result["parity_full_depth_db"] = par
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         plan = "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04))
