@@ -81,6 +81,90 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const uint16_t* __rest
     }
 }
 
+// Round 5: the same arithmetic with ONE WAVE per row (4 rows per 256-thread block), for d a multiple of 512.  The row stays in registers
+// as the bf16 bits it arrived in (NV uint4 per lane: 24 VGPRs at d = 3072 - the round-4 attempt kept 48 fp32 values per lane and lost
+// its occupancy) and is widened on the fly in each of the three passes; no LDS, no block barriers, every thread has the same amount of
+// work (the block-per-row kernel above gives threads 0-127 two vectors of a 3072-wide row and threads 128-255 one).  Sums run per lane
+// over its NV x 8 elements, then across the wave (xor butterfly): another fp32 summation order than the block kernel's (same box A/B,
+// profiles/r05_ln_wave_ab.txt: 8704 x 3072 rows 25.8 -> 20.7 us = 4.15 -> 5.16 TB/s, 33280 rows 92 -> 74 us; 4 outputs in a million
+// differ, by one bf16 ulp).
+template <int NV>
+__global__ __launch_bounds__(256) void ln_modulate_wave_kernel(const uint16_t* __restrict__ x, int ldx, uint16_t* __restrict__ out, int ldo,
+                                                               int M, float eps, const LnSegs segs) {
+    constexpr int d = NV * 512;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    int si = 0;
+#pragma unroll
+    for (int i = 0; i < LN_MAXSEG - 1; ++i) si += (row >= segs.end[i]) ? 1 : 0;
+    const uint16_t* sh = segs.shift[si];
+    const uint16_t* sc = segs.scale[si];
+    const uint16_t* xr = x + (size_t)row * ldx + lane * 8;
+    uint4 xv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xv[i] = *(const uint4*)(xr + i * 512);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const uint32_t w[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s += __uint_as_float(w[k] << 16); s += __uint_as_float(w[k] & 0xffff0000u); }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const uint32_t w[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float c0 = __uint_as_float(w[k] << 16) - mean, c1 = __uint_as_float(w[k] & 0xffff0000u) - mean;
+            q += c0 * c0;
+            q += c1 * c1;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    uint16_t* orow = out + (size_t)row * ldo + lane * 8;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const uint4 a4 = *(const uint4*)(sc + lane * 8 + i * 512), b4 = *(const uint4*)(sh + lane * 8 + i * 512);
+        const uint32_t w[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float y[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float xe = __uint_as_float(h ? (w[k] & 0xffff0000u) : (w[k] << 16));
+                const float ae = __uint_as_float(h ? (a[k] & 0xffff0000u) : (a[k] << 16));
+                const float be = __uint_as_float(h ? (b[k] & 0xffff0000u) : (b[k] << 16));
+                const float y0 = rbf((xe - mean) * rstd);          // LayerNorm output (bf16)
+                const float s1 = rbf(1.0f + ae);                   // (1 + scale) (bf16)
+                y[h] = rbf(y0 * s1) + be;
+            }
+            o[k] = f2bf_pk(y[0], y[1]);
+        }
+        *(uint4*)(orow + i * 512) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int launch_ln(const uint16_t* x, int ldx, uint16_t* out, int ldo, int M, int d, float eps, const LnSegs& segs, hipStream_t st) {
+    if (d % 512 == 0) {          // the wave-per-row kernel; other widths (toy trunks, d = 256): the block-per-row kernel below
+        const dim3 grid((M + 3) / 4), blk(256);
+        switch (d / 512) {
+            case 1: hipLaunchKernelGGL(ln_modulate_wave_kernel<1>, grid, blk, 0, st, x, ldx, out, ldo, M, eps, segs); return check_launch("ln_modulate_wave_kernel");
+            case 2: hipLaunchKernelGGL(ln_modulate_wave_kernel<2>, grid, blk, 0, st, x, ldx, out, ldo, M, eps, segs); return check_launch("ln_modulate_wave_kernel");
+            case 3: hipLaunchKernelGGL(ln_modulate_wave_kernel<3>, grid, blk, 0, st, x, ldx, out, ldo, M, eps, segs); return check_launch("ln_modulate_wave_kernel");
+            case 4: hipLaunchKernelGGL(ln_modulate_wave_kernel<4>, grid, blk, 0, st, x, ldx, out, ldo, M, eps, segs); return check_launch("ln_modulate_wave_kernel");
+            case 6: hipLaunchKernelGGL(ln_modulate_wave_kernel<6>, grid, blk, 0, st, x, ldx, out, ldo, M, eps, segs); return check_launch("ln_modulate_wave_kernel");
+            case 8: hipLaunchKernelGGL(ln_modulate_wave_kernel<8>, grid, blk, 0, st, x, ldx, out, ldo, M, eps, segs); return check_launch("ln_modulate_wave_kernel");
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, st, x, ldx, out, ldo, d, eps, segs);
+    return check_launch("ln_modulate_kernel");
+}
+
 // ------------------------------------------------------------------------------------------------
 // Q/K: per-head RMSNorm + RoPE.  One wave per token row, lane = one rotary pair (2 of 128 dims),
 // loop over heads so the cos/sin pairs are loaded once per row.
@@ -226,9 +310,7 @@ int rgn_ln_modulate(const void* x, int ldx, void* out, int ldo, int M, int d, fl
         segs.shift[i] = (const uint16_t*)(i == 0 && split_row > 0 ? shift0 : shift1);
         segs.scale[i] = (const uint16_t*)(i == 0 && split_row > 0 ? scale0 : scale1);
     }
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
-                       (uint16_t*)out, ldo, d, eps, segs);
-    return check_launch("ln_modulate_kernel");
+    return launch_ln((const uint16_t*)x, ldx, (uint16_t*)out, ldo, M, d, eps, segs, (hipStream_t)stream);
 }
 
 int rgn_ln_modulate_segs(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, int nseg, const int* seg_end_host,
@@ -248,9 +330,7 @@ int rgn_ln_modulate_segs(const void* x, int ldx, void* out, int ldo, int M, int 
         prev = seg_end_host[j];
     }
     if (seg_end_host[nseg - 1] != M) return fail(RGN_E_BADARG, "ln_modulate_segs: the last segment must end at M");
-    hipLaunchKernelGGL(ln_modulate_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, ldx,
-                       (uint16_t*)out, ldo, d, eps, segs);
-    return check_launch("ln_modulate_kernel");
+    return launch_ln((const uint16_t*)x, ldx, (uint16_t*)out, ldo, M, d, eps, segs, (hipStream_t)stream);
 }
 
 int rgn_rms_norm_rows(const void* x, int ldx, const void* w, void* out, int ldo, int M, int d, float eps, void* stream) {

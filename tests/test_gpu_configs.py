@@ -68,8 +68,9 @@ def test_config3_flux_1024_true_cfg6_full_size(golden):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("weights", [pytest.param("bf16", marks=pytest.mark.gpu_long), pytest.param("fp8", marks=pytest.mark.gpu)])
-def test_config4_step1x_v1p2_2048_50_steps(golden, weights):
+@pytest.mark.parametrize("weights,depth", [pytest.param("bf16", None, marks=pytest.mark.gpu_long), pytest.param("fp8", None, marks=pytest.mark.gpu_long),
+                                           pytest.param("fp8", (2, 4), marks=pytest.mark.gpu)])
+def test_config4_step1x_v1p2_2048_50_steps(golden, weights, depth):
     """L = L_c = 16384 (S = 33280 / 33152 rows per branch), 50 denoising steps, tagged sequential CFG 6.0 with text
     lengths 512 / 384, one K/V cache per branch (2 x 23 GB).  `weights="fp8"`: the trunk's GEMM weights are OCP e4m3
     with per-output-channel scales (BASELINE configs[4] "fp8 weights"), activations stay bf16."""
@@ -79,7 +80,10 @@ def test_config4_step1x_v1p2_2048_50_steps(golden, weights):
     from regione_amd.tool.RegionE import resample_gamma
     from tools.run_configs import weights_stream, make_box
     dev = torch.device("cuda", 0)
-    cfg = synth.FluxConfig(guidance_embeds=False)
+    # depth None = the trunk's 19 + 38 blocks (one edit = 36 s of GPU time: -m gpu_long, and tools/run_configs.py for the timing in
+    # profiles/); (2, 4) = the same widths, sequence lengths, 50-step plan and two 2 x L caches on a 6-block trunk for the -m gpu suite -
+    # every property checked below is independent of the depth
+    cfg = synth.FluxConfig(guidance_embeds=False) if depth is None else synth.FluxConfig(guidance_embeds=False, n_double=depth[0], n_single=depth[1])
     tr = HS.Step1XEditTransformer2DModel(cfg, dev).load_state_dict_stream(weights_stream(cfg, dev, 42))
     if weights == "fp8":
         if not hasattr(tr, "quantize_fp8_"):
