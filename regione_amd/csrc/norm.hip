@@ -170,6 +170,19 @@ static int launch_ln(const uint16_t* x, int ldx, uint16_t* out, int ldo, int M, 
 // loop over heads so the cos/sin pairs are loaded once per row.
 //   q: in place.   k: -> K slab row (kv_rows ? kv_rows[m] : m), rotated with the FULL-id table.
 // ------------------------------------------------------------------------------------------------
+// Sum of the 64 lanes' values in the order the fused Q/K/V epilogue of the GEMM uses (gemm.hip: qk_norm_rope_vec - there a lane holds
+// FOUR rotary pairs and adds them before its 16-lane butterfly): neighbours 2 and 1 apart first, then 32, 16, 8, 4.  Every lane ends
+// with the same value; the two paths agree bit for bit (tests/test_gpu_kernels.py).
+__device__ __forceinline__ float head_sum(float v) {
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 32, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict__ qkv, int ld, int k_col, int q_col,
                                                            int M, int H, int split_row,
                                                            const uint16_t* __restrict__ wq0, const uint16_t* __restrict__ wk0,
@@ -200,8 +213,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(uint16_t* __restrict_
         const uint32_t kv = *(const uint32_t*)(row + k_col + h * 128 + lane * 2);
         float qa = bf2f(qv & 0xffff), qb = bf2f(qv >> 16), ka = bf2f(kv & 0xffff), kb = bf2f(kv >> 16);
         // RMSNorm: fp32 variance, x*rsqrt in fp32, round to bf16, times bf16 weight (round)
-        const float rq = 1.0f / sqrtf(wave_sum(qa * qa + qb * qb) * (1.0f / 128.0f) + eps);
-        const float rk = 1.0f / sqrtf(wave_sum(ka * ka + kb * kb) * (1.0f / 128.0f) + eps);
+        const float rq = 1.0f / sqrtf(head_sum(qa * qa + qb * qb) * (1.0f / 128.0f) + eps);
+        const float rk = 1.0f / sqrtf(head_sum(ka * ka + kb * kb) * (1.0f / 128.0f) + eps);
         qa = rbf(rbf(qa * rq) * wq_a); qb = rbf(rbf(qb * rq) * wq_b);
         ka = rbf(rbf(ka * rk) * wk_a); kb = rbf(rbf(kb * rk) * wk_b);
         // RoPE (fp32): out[2i] = x[2i]*cos - x[2i+1]*sin ; out[2i+1] = x[2i+1]*cos + x[2i]*sin
