@@ -64,7 +64,7 @@ constexpr float DEFER_THR = 8.0f;              // log2 units: P <= 2^8 before th
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     bf2_t r = __builtin_convertvector(f32x2{a, b}, bf2_t);     // v_cvt_pk_bf16_f32 (RNE)
-    return *(uint32_t*)&r;
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 template <int N>

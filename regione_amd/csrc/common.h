@@ -31,7 +31,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
 typedef __attribute__((ext_vector_type(2))) float hw_f32x2;
 __device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
     hw_bf16x2 r = __builtin_convertvector(hw_f32x2{lo, hi}, hw_bf16x2);
-    return *(uint32_t*)&r;
+    return __builtin_bit_cast(uint32_t, r);
 }
 __device__ __forceinline__ uint16_t f2bf(float f) { return (uint16_t)f2bf_pk(f, 0.f); }
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

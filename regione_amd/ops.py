@@ -63,6 +63,9 @@ def arp_partition(sample: torch.Tensor, model_output: Optional[torch.Tensor], co
     mo = _rows(model_output) if model_output is not None else None
     L, D = s.shape
     dev = s.device
+    if c.shape != s.shape or (mo is not None and mo.shape != s.shape) or h_tok * w_tok != L:
+        raise _lib.RegionEHipError(f"arp_partition: sample {tuple(s.shape)}, model_output {None if mo is None else tuple(mo.shape)}, cond "
+                                   f"{tuple(c.shape)} must all be [L, D] with L = h_tok * w_tok = {h_tok * w_tok}")
     e = torch.empty(L, dtype=torch.int64, device=dev)
     u = torch.empty(L, dtype=torch.int64, device=dev)
     raw = torch.empty(L, dtype=torch.uint8, device=dev)
@@ -107,6 +110,8 @@ def scatter_rows_(src: torch.Tensor, ids: torch.Tensor, dst: torch.Tensor) -> to
     """ids_scatter: dst[ids[k]] = src[k] in place; returns dst."""
     s, d = _rows(src), _rows(dst)
     idv = ids.reshape(-1).contiguous()
+    if idv.dtype != torch.int64 or idv.numel() > s.shape[0] or s.shape[1] != d.shape[1] or s.dtype != d.dtype:
+        raise _lib.RegionEHipError(f"scatter_rows_: {idv.numel()} {idv.dtype} ids for {s.shape[0]} source rows of width {s.shape[1]} -> {d.shape[1]}")
     rc = _lib.lib().rgn_scatter_rows(_p(s), _p(idv), _p(d), idv.numel(), s.shape[1] * s.element_size(), _stream())
     _lib.check(rc, "rgn_scatter_rows")
     return dst
@@ -276,6 +281,12 @@ def gemm_pair(A0, W0, b0, out0, A1, W1, b1, out1, *, epilogue: int = EPI_BIAS, g
     _lib.check(rc, "rgn_gemm_bf16_pair")
 
 
+def _check_bias(bias, N: int, dev, what: str):
+    """The kernels read `bias` as bf16 [N] (8-byte vectors): the C ABI cannot know its length."""
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.dim() != 1 or bias.numel() != N or not bias.is_contiguous() or bias.device != dev):
+        raise _lib.RegionEHipError(f"{what}: bias must be bf16 [{N}], contiguous, on {dev} (got {bias.dtype} {tuple(bias.shape)} on {bias.device})")
+
+
 def qkv_epilogue(*, wq, wk, rope_q, rope_k, k_slab, vt_slab, H: int, k_col: int, v_col: int, q_col: int,
                  kv_rows: Optional[torch.Tensor] = None, row_base: int = 0, eps: float = 1e-6, fp16_roundtrip: bool = False,
                  rows: Optional[int] = None):
@@ -318,6 +329,7 @@ def gemm_qkv(A: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor], out
     M, K = A.shape
     N = W.shape[0]
     assert A.stride(1) == 1 and W.stride(1) == 1 and out.stride(1) == 1 and W.shape[1] == K and out.shape[1] == N
+    _check_bias(bias, N, A.device, "gemm_qkv")
     ws = gemm_workspace(A.device)
     sc = _wscale(W)
     if sc is not None:
@@ -338,6 +350,8 @@ def gemm_qkv_pair(A0, W0, b0, out0, epi0, A1, W1, b1, out1, epi1):
     assert A0.shape[1] == K and A1.shape[1] == K and out0.shape[1] == N and out1.shape[1] == N
     for t in (A0, A1, out0, out1):
         assert t.stride(1) == 1 and t.dtype == torch.bfloat16
+    _check_bias(b0, N, A0.device, "gemm_qkv_pair")
+    _check_bias(b1, N, A0.device, "gemm_qkv_pair")
     ws = gemm_workspace(A0.device)
     s0, s1 = _wscale(W0), _wscale(W1)
     if s0 is not None or s1 is not None:
@@ -376,6 +390,7 @@ def gemm_group(problems, *, epilogue: int = EPI_BIAS, gelu_from_col: int = 0):
             assert t.stride(1) == 1 and t.dtype == torch.bfloat16
         if p.resid is not None:
             assert p.resid.stride(0) == p.out.stride(0) and p.resid.stride(1) == 1
+        _check_bias(p.bias, N, p.A.device, "gemm_group")
         g = arr[i]
         g.A, g.W, g.wscale, g.bias, g.C = _p(p.A), _p(p.W), _p(_wscale(p.W)), _p(p.bias), _p(p.out)
         g.gate, g.resid = _p(p.gate), _p(p.resid)

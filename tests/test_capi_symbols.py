@@ -72,3 +72,52 @@ def test_argument_validation_returns_codes_and_messages_without_touching_the_gpu
     assert h.rgn_qk_norm_rope_store(P, 12, 0, 0, 0, 8, 2, 0, None, None, P, P, 1e-6, P, P, P, P, None, P, P, 64, None) < 0
     assert h.rgn_gather_rows(None, P, P, 4, 128, None) < 0
     assert h.rgn_gemv_bf16(P, 64, P, None, P, 64, 9, 64, 64, 0, None) < 0                 # batch > 4
+    # round-5 entries
+    assert h.rgn_add_bf16(None, P, P, 8, None) < 0 and h.rgn_add_bf16(P, P, P, 0, None) == 0
+    assert h.rgn_sel_rows(None, 4, 8, P, None) < 0 and h.rgn_sel_rows(P, -1, 8, P, None) < 0 and h.rgn_sel_rows(None, 0, 0, P, None) == 0
+    assert h.rgn_fill_zero(None, 16, None) < 0 and h.rgn_fill_zero(None, 0, None) == 0
+
+
+def test_abi_stamp_and_plan_override_hook():
+    """The library reports the header's ABI version and the struct sizes the ctypes mirrors were written for (a binding built against
+    another header refuses to run, regione_amd/torch_ops.py); the launch-plan hook knows exactly the documented knobs."""
+    import ctypes as C
+    h = _lib.lib()
+    text = open(os.path.join(ROOT, "include", "regione_hip.h")).read()
+    assert h.rgn_version() == int(re.search(r"#define RGN_ABI_VERSION (\d+)", text).group(1))
+    assert h.rgn_abi_struct_bytes() == C.sizeof(_lib.QkvEpilogue) * 1000 + C.sizeof(_lib.GemmProblem)
+    for k in _lib.PLAN_KEYS:
+        assert h.rgn_plan_override(k.encode(), 1) == 0 and h.rgn_plan_override(k.encode(), -1) == 0
+    assert h.rgn_plan_override(b"RGN_GEMM_VARIANT", 1) < 0 and b"unknown key" in h.rgn_last_error()
+    assert h.rgn_plan_override(None, 0) == 0
+    with _lib.plan_override(gemm_pieces=1):
+        pass
+    with pytest.raises(_lib.RegionEHipError):
+        with _lib.plan_override(no_such_knob=1):
+            pass
+
+
+def test_a_binding_built_against_another_header_is_refused(tmp_path):
+    """regione_amd/torch_ops.py compares the C++ binding's compiled-in ABI stamp with the HIP library's before any op can run."""
+    import subprocess, sys, textwrap
+    if not os.path.exists(os.path.join(ROOT, "regione_amd", "lib", "libregione_torch.so")):
+        pytest.skip("C++ binding not built")
+    code = textwrap.dedent("""
+        import ctypes, sys
+        sys.path.insert(0, %r)
+        from regione_amd import _lib
+        h = _lib.lib()
+        real = h.rgn_version
+        class Fake:                                   # the HIP library as a NEWER build would answer
+            def __getattr__(self, n): return getattr(h, n)
+            def rgn_version(self): return real() + 1
+        _lib._lib = Fake()
+        try:
+            import regione_amd.torch_ops
+        except _lib.RegionEHipError as e:
+            print("REFUSED", "rebuild" in str(e))
+        else:
+            print("LOADED")
+    """ % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RGN_TORCH_OPS="cpp"))
+    assert "REFUSED True" in r.stdout, r.stdout + r.stderr

@@ -175,6 +175,82 @@ def test_ops_refuse_arguments_the_kernels_would_misread():
 
 
 @pytest.mark.gpu
+def test_projection_ops_check_extents_not_only_dtypes():
+    """Advisor finding, round 4: the fused Q/K/V ops read cos / sin at rows [row_base, row_base + M), kv_rows[row_base + m] and identity
+    cache rows up to row_base + M - a table, an id list or a slab that is too short must be an error (TORCH_CHECK / RegionEHipError on the
+    Python registration), never an out-of-bounds device read or K / V scattered into arbitrary cache rows.  The valid call runs."""
+    from regione_amd import ops
+    H, K, M = 2, 256, 96
+    d = H * 128
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.randn(M, K, generator=g, device=dev).bfloat16()
+    w = (torch.randn(3 * d, K, generator=g, device=dev) * 0.05).bfloat16()
+    b = torch.randn(3 * d, generator=g, device=dev).bfloat16()
+    nq = nk = torch.ones(128, device=dev).bfloat16()
+    skv = 128
+    mk = lambda rows: (torch.rand(rows, 128, device=dev).contiguous(), torch.rand(rows, 128, device=dev).contiguous())
+    cos, sin = mk(skv)
+    kc = torch.zeros(ops.padded(skv), d, dtype=torch.bfloat16, device=dev)
+    vc = torch.zeros(d, ops.padded(skv), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros(M, 3 * d, dtype=torch.bfloat16, device=dev)
+    call = lambda **kw: torch.ops.regione_mi.kv_partial_update_(
+        kw.get("x", x), w, kw.get("b", b), kw.get("out", out), nq, nk, kw.get("cos", cos), kw.get("sin", sin), kw.get("cos", cos), kw.get("sin", sin),
+        kw.get("rows"), kc, vc, H, kw.get("row_base", 0))
+    call()                                                       # valid: identity rows 0 .. 95 of a 128-row slab
+    short = mk(M - 1)
+    with pytest.raises(RuntimeError):
+        call(cos=short[0], sin=short[1])                         # rotary table one row short
+    with pytest.raises(RuntimeError):
+        call(row_base=64)                                        # rows 64 .. 159: past the table and the slab
+    with pytest.raises(RuntimeError):
+        call(rows=torch.arange(M - 8, device=dev))               # kv_rows shorter than the problem
+    with pytest.raises(RuntimeError):
+        call(b=b[:-8].contiguous())                              # bias is not [N]
+    with pytest.raises(RuntimeError):
+        call(b=b.float())                                        # bias dtype
+    with pytest.raises(RuntimeError):
+        torch.ops.regione_mi.scatter_rows_(torch.zeros(1, 4, 64, device=dev), torch.arange(6, device=dev)[None], torch.zeros(1, 16, 64, device=dev))
+    with pytest.raises(RuntimeError):
+        torch.ops.regione_mi.arp_partition(torch.zeros(1, 64, 64, device=dev), torch.zeros(1, 32, 64, device=dev), torch.zeros(1, 64, 64, device=dev),
+                                           -0.5, 0.9, 8, 8, True)
+    call(rows=torch.arange(M, device=dev))                       # and a valid gathered call
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_small_round5_entries_match_torch():
+    """rgn_add_bf16 / rgn_sel_rows / rgn_fill_zero / ops.cat_rows and the never-materialised [latents ; image_latents] of the x_embedder."""
+    from regione_amd import ops
+    from regione_amd.harness import flux as H
+    g = torch.Generator(device="cuda").manual_seed(1)
+    a = torch.randn(3, 3072, generator=g, device="cuda").bfloat16()
+    b = torch.randn(3, 3072, generator=g, device="cuda").bfloat16()
+    assert torch.equal(ops.add_bf16(a, b), a + b)
+    c = a.clone()
+    assert torch.equal(ops.add_bf16(c, b, out=c), a + b)                               # in place
+    ids = torch.randperm(4096, generator=g, device="cuda")[:777].sort().values[None]
+    assert torch.equal(ops.sel_rows(ids, 512), torch.cat((torch.arange(512, device="cuda"), ids[0] + 512)))
+    assert ops.sel_rows(ids[:, :0], 7).tolist() == list(range(7))
+    z = ops.zeros((300, 257), dtype=torch.bfloat16)
+    assert z.shape == (300, 257) and not z.any()
+    parts = [torch.randn(1, n, 64, generator=g, device="cuda").bfloat16() for n in (100, 37, 256)]
+    assert torch.equal(ops.cat_rows(parts, dim=1), torch.cat(parts, dim=1))
+    assert torch.equal(ops.cat_rows([p[0] for p in parts], dim=0), torch.cat([p[0] for p in parts], dim=0))
+    # RowCat: shape protocol, batch repeat, and the x_embedder's group launch == the GEMM on the materialised concatenation
+    rc = H.RowCat(parts[:2])
+    assert rc.shape == (1, 137, 64) and rc.size(1) == 137 and rc.dtype == torch.bfloat16 and H.repeat_batch(rc, 2)[1:2].shape == (1, 137, 64)
+    assert torch.equal(rc.materialise(), torch.cat(parts[:2], dim=1))
+    W = (torch.randn(256, 64, generator=g, device="cuda") * 0.1).bfloat16()
+    bias = torch.randn(256, generator=g, device="cuda").bfloat16()
+    o1 = torch.empty(137, 256, dtype=torch.bfloat16, device="cuda")
+    o2 = torch.empty_like(o1)
+    ops.gemm_group(H._x_problems(rc, W, bias, o1))
+    ops.gemm(rc.materialise()[0], W, bias, o2)
+    assert torch.equal(o1, o2)
+
+
+@pytest.mark.gpu
 def test_engine_runs_on_the_registered_op_surface():
     """One toy 28-step RegionE edit under a dispatch recorder: the ops SURVEY.md 8(b) names are the ones the product's
     patch set and attention processors actually dispatch (not a side registration next to a ctypes path)."""

@@ -1,4 +1,7 @@
 #!/bin/bash
+# HISTORICAL (ran at commit a185b89; output = profiles/r05_gemm_store_loop_ab.txt): the `gemm_persistent` knob and the old-store-loop
+# library build it compares no longer exist (the persistent loop measured neutral and was removed in b06e038).  Kept as the record of
+# how the A/B was made; to re-run, check out a185b89.
 # round-5 same-box A/B of the GEMM epilogue's store loop and the persistent tile loop:
 #   old   = the round-4 store loop (join-point `s_waitcnt vmcnt(0)` in front of every C store), one workgroup per tile
 #   fast  = load-free store loop instance, one workgroup per tile          (RGN_PLAN_OVERRIDE=gemm_persistent=0)
