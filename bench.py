@@ -244,16 +244,15 @@ def physical_cores():
 
 
 def csrc_hash():
-    """sha256 of the kernel sources: stamps the PMC files so that bench.py only quotes traffic measured on THIS build."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "regione_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if not f.endswith((".hip", ".inc", ".h")):          # kernel sources only (the torch binding is host C++)
-            continue
-        h.update(f.encode())
-        h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """sha256 of the kernel sources: stamps the PMC files so that bench.py only quotes traffic measured on THIS build (the same hash
+    build_lib() writes beside the library and _lib.lib() checks at load)."""
+    from regione_amd.build import csrc_hash as h
+    return h()
+
+
+def _built_from():
+    from regione_amd.build import built_from
+    return built_from()
 
 
 def load_stamped(rel_path, stamp=None):
@@ -544,6 +543,8 @@ def main():
                    "images_per_gpu": 1, "parallelism": f"image-sharded x{world}",
                    "params_billion": round(sum(int(torch.tensor(s).prod()) for s in synth.flux_param_shapes(cfg).values()) / 1e9, 2)},
         "edit_wall_clock_s": edit_s,
+        "native_library": {"path": os.path.relpath(ops._lib.LIB_PATH, ROOT), "abi_version": int(ops._lib.lib().rgn_version()),
+                           "kernel_sources_sha16": csrc_hash(), "built_from_sha16": _built_from()},
         "algorithmic_tflop_per_edit": flops_edit / 1e12,
         "loop_mfma_frac": flops_edit / edit_s / 1e12 / PEAK_BF16_TFLOPS,
         "model_build_s": t_build,

@@ -13,6 +13,7 @@ import os
 # runtimes then disagree about the device: "no ROCm-capable device is detected").
 import torch  # noqa: F401
 
+from . import build as _build
 from .build import LIB_PATH
 
 # developer A/B switch: load another build of the SAME C ABI (never a fallback - it must exist)
@@ -124,6 +125,13 @@ def lib():
         raise RegionEHipError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); there is no CPU fallback.")
+    if os.path.abspath(LIB_PATH) == os.path.abspath(_build.LIB_PATH) and os.path.isdir(_build.CSRC):
+        # the in-tree library beside its sources: it must be the build of THESE sources (a stale .so would make every measurement and
+        # parity claim about the tree a claim about something else)
+        built, now = _build.built_from(), _build.csrc_hash()
+        if built and built != now:
+            raise RegionEHipError(f"{LIB_PATH} was built from kernel sources {built}, the tree holds {now}: rebuild with "
+                                  "`python -m regione_amd.build` (or `__graft_entry__.build()`)")
     h = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(h, name)           # AttributeError if the symbol is missing: loud by design

@@ -23,8 +23,34 @@ TORCH_SRC = os.path.join(CSRC, "torch_binding.cpp")
 HEADER = os.path.join(HERE, "..", "include", "regione_hip.h")
 
 
+STAMP_PATH = os.path.join(LIB_DIR, "libregione_hip.stamp")
+
+
+def csrc_hash() -> str:
+    """sha256 (16 hex digits) of the kernel sources (.hip / .inc / .h under csrc/; the torch binding is host C++): written beside the
+    library it was built from (`libregione_hip.stamp`), stamped into the committed counter files (bench.py), checked at load (_lib.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith((".hip", ".inc", ".h")):
+            continue
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def built_from() -> str:
+    """The source hash the in-tree library was built from ('' when there is no stamp)."""
+    try:
+        return open(STAMP_PATH).read().strip()
+    except OSError:
+        return ""
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB_PATH):
+        return True
+    if built_from() != csrc_hash():              # content, not only mtime: a checkout can restore sources with any timestamp
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.endswith(".cpp")] + [HEADER]
@@ -59,6 +85,8 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP_PATH, "w") as f:
+        f.write(csrc_hash() + "\n")
     return LIB_PATH
 
 

@@ -121,3 +121,19 @@ def test_a_binding_built_against_another_header_is_refused(tmp_path):
     """ % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RGN_TORCH_OPS="cpp"))
     assert "REFUSED True" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_in_tree_library_is_the_build_of_the_tree_sources(monkeypatch):
+    """build_lib() stamps the library with the hash of the kernel sources it compiled (the hash the committed counter files carry);
+    staleness is decided on content, and _lib.lib() refuses an in-tree library whose stamp names other sources - a stale .so would
+    make every parity and bench statement about this tree a statement about something else."""
+    from regione_amd import _lib, build
+    assert build.built_from() == build.csrc_hash(), "conftest builds the library: the stamp must name the current sources"
+    assert not build._stale()
+    monkeypatch.setattr(build, "built_from", lambda: "0123456789abcdef")
+    assert build._stale()
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.RegionEHipError, match="rebuild"):
+        _lib.lib()
+    monkeypatch.undo()
+    assert _lib.lib() is not None

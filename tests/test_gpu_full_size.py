@@ -212,6 +212,8 @@ def test_bench_json_contract_single_gpu():
     assert d["unit"] == "steps/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    nl = d["native_library"]                     # the in-tree library, built from the kernel sources of this tree
+    assert nl["path"].endswith("regione_amd/lib/libregione_hip.so") and nl["built_from_sha16"] == nl["kernel_sources_sha16"] != ""
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert "traffic" in rf and "mfma_busy" in rf
