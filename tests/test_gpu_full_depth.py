@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-# 35-80 s of CPU oracle each (the host's load decides): both run under -m gpu_long; `-m gpu` keeps the three 28-step loops at depth and
+# 35-80 s of CPU oracle each (the host's load decides): both run under -m gpu_long; `-m gpu` keeps the FLUX and Qwen 28-step loops at depth and
 # tests/test_gpu_full_dims.py's FLUX blocks at full dimensions.  The same function at the HEADLINE shape (64 x 64 grid, T = 512,
 # K_e = 1024) is the tool run profiles/r05_parity_headline.json (~5 min of CPU oracle).
 @pytest.mark.gpu_long
@@ -39,8 +39,8 @@ def test_full_depth_full_width_full_store_then_region_step_vs_oracle(family):
     assert r["untouched_rows_bit_identical"]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("family", ["flux", "qwen", "step1x_v1p2"])
+@pytest.mark.parametrize("family", [pytest.param("flux", marks=pytest.mark.gpu), pytest.param("qwen", marks=pytest.mark.gpu),
+                                    pytest.param("step1x_v1p2", marks=pytest.mark.gpu_long)])     # 17 s of CPU oracle: the long set
 def test_full_depth_trunk_28_steps_vs_oracle_denoise(family):
     """FLUX and Step1X-Edit v1p2: the north star's 40 dB, hard.  Qwen is the ONE explicit exception (advisor, round 4): 60 blocks and
     a norm-preserving CFG combine `neg + 4 (pos - neg)` put the oracle's own re-ordered run 39.9 dB from itself, so the bar for
