@@ -42,7 +42,7 @@ N_STEPS = 28
 # hash of the kernel sources this process runs (load_stamped)
 PMC_TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"
 PMC_MFMA_FILE = "profiles/r05_pmc_mfma.json"
-PARITY_FILES = ("profiles/r05_parity_headline.json", "profiles/r05_parity_full_depth.json")
+PARITY_FILES = ("profiles/r06_parity_headline.json", "profiles/r06_parity_full_depth.json")
 
 
 def algorithmic_flops(cfg, T, N, K_e):
@@ -411,9 +411,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (one process per GPU, rendezvous on 127.0.0.1 - the container hostname
+        # may not resolve); under torch.distributed.run this branch is never taken.  One JSON line either way (rank 0 prints it).
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (torch.distributed.run --nproc-per-node "
+                         f"{args.gpus}) or run plain `python bench.py --gpus {args.gpus}`, which launches them itself")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.share_gpu:
         local_rank = 0
@@ -640,9 +653,13 @@ def main():
         # -m gpu suite re-runs the 16 x 16-grid cases with assertions): round 5 = the HEADLINE shape itself (L = 4096, T = 512, K_e = 1024,
         # 57 blocks, d = 3072: one FULL step with store + one REGION step) and the 28-step loops at full width AND depth; round 4 = the
         # d = 512 loops and the 16 x 16-grid full-width steps
-        par = {"sources": [f for f in PARITY_FILES + ("profiles/r04_parity_full_depth.json",) if os.path.exists(os.path.join(ROOT, f))]}
+        par = {"note": "committed reports of tools/parity_full_depth.py (the -m gpu suite asserts the same cases); NOT measured in this run",
+               "sources": [f for f in PARITY_FILES if os.path.exists(os.path.join(ROOT, f))]}
         for f in par["sources"]:
-            for c in json.load(open(os.path.join(ROOT, f)))["cases"]:
+            rep = json.load(open(os.path.join(ROOT, f)))
+            label = {"source": f, "measured_in_this_run": False, "csrc_sha16": rep.get("csrc_sha16"),
+                     "stale": rep.get("csrc_sha16") != csrc_hash()}          # measured on other kernel sources than the ones running
+            for c in rep["cases"]:
                 name = c["case"]
                 if "rows" in c:
                     par[name] = {"min_psnr_db": min(r["psnr_hip_vs_oracle_db"] for r in c["rows"]), "blocks": c["blocks"], "d": c["d"],
@@ -657,7 +674,8 @@ def main():
                     w = c.get("worst_combined_step")
                     if w:          # true-CFG families: where the combined velocity's distance comes from (per-branch vs combine)
                         par[name]["worst_step_branch_attribution_db"] = {k: w[k] for k in ("step", "psnr_cond_db", "psnr_uncond_db", "psnr_combined_db")}
-        if len(par) > 1:
+                par[name].update(label)
+        if len(par) > 2:
             result["parity_full_depth_db"] = par
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         plan = "".join(O.derive_schedule(L, "flux", 6, 2, "16", 0.04))

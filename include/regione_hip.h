@@ -48,6 +48,9 @@ const char* rgn_last_error(void);
  * threads.  The same knobs can be preset once per process with RGN_PLAN_OVERRIDE="key=value,key=value" - the only environment
  * variable libregione_hip.so reads, at the first launch.  Results never depend on a knob beyond fp32 summation order. */
 int rgn_plan_override(const char* key, int value);
+/* The current value of one knob (-1 = not forced), so that a scoped override can restore what it found instead of resetting
+ * (nested scopes, a process preset through RGN_PLAN_OVERRIDE). */
+int rgn_plan_override_get(const char* key, int* value);
 /* The launch plan the GEMM planner chose for the last rgn_gemm_* call on this thread (introspection for tests and traces; the
  * reference has no counterpart): bits 0-7 = K pieces of the remainder (1 = none), bit 8 = quarter-tile remainder, bit 10 =
  * 256 x 256 tile geometry. */

@@ -47,6 +47,7 @@ SIGNATURES = {
     "rgn_version": [],
     "rgn_abi_struct_bytes": [],
     "rgn_plan_override": [C.c_char_p, _c_int],
+    "rgn_plan_override_get": [C.c_char_p, C.POINTER(C.c_int)],
     "rgn_gemm_last_plan": [],
     "rgn_attention_last_plan": [],
     "rgn_attention_plan_query": [_c_int, _c_int, _c_int, C.c_size_t],
@@ -154,17 +155,21 @@ PLAN_KEYS = ("gemm_pieces", "gemm_geometry", "gemm_asm", "gemm_quarter", "attn_w
 @_contextlib.contextmanager
 def plan_override(**knobs):
     """Force launch-plan knobs for the duration of a `with` block (rgn_plan_override, include/regione_hip.h) - tests and sweep
-    tools only; every knob returns to -1 (= the cost models decide) on exit.
+    tools only; every knob returns to the value it HAD on exit (nested blocks and an RGN_PLAN_OVERRIDE preset survive).
 
         with _lib.plan_override(gemm_pieces=3, gemm_geometry=256): ops.gemm(...)"""
     h = lib()
-    for k, v in knobs.items():
-        check(h.rgn_plan_override(k.encode(), int(v)), f"rgn_plan_override({k})")
+    before = {}
     try:
+        for k, v in knobs.items():
+            old = C.c_int(-1)
+            check(h.rgn_plan_override_get(k.encode(), C.byref(old)), f"rgn_plan_override_get({k})")
+            check(h.rgn_plan_override(k.encode(), int(v)), f"rgn_plan_override({k})")
+            before[k] = old.value
         yield
     finally:
-        for k in knobs:
-            h.rgn_plan_override(k.encode(), -1)
+        for k, old in before.items():
+            h.rgn_plan_override(k.encode(), old)
 
 
 def check(rc: int, what: str = ""):

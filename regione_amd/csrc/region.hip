@@ -320,13 +320,19 @@ __global__ void sel_rows_kernel(const int64_t* __restrict__ ids, int K, int T, i
     else if (i < T + K) out[i] = (int64_t)T + ids[i - T];
 }
 
-static bool plan_set(PlanOverride& o, const char* key, int value) {
+static int* plan_field(PlanOverride& o, const char* key) {
     struct { const char* name; int* field; } tab[] = {
         {"gemm_pieces", &o.gemm_pieces}, {"gemm_geometry", &o.gemm_geometry}, {"gemm_asm", &o.gemm_asm}, {"gemm_quarter", &o.gemm_quarter},
         {"attn_waves", &o.attn_waves}, {"attn_split", &o.attn_split}, {"attn_streamk", &o.attn_streamk}, {"attn_asm", &o.attn_asm}};
     for (auto& t : tab)
-        if (strcmp(t.name, key) == 0) { *t.field = value; return true; }
-    return false;
+        if (strcmp(t.name, key) == 0) return t.field;
+    return nullptr;
+}
+
+static bool plan_set(PlanOverride& o, const char* key, int value) {
+    int* f = plan_field(o, key);
+    if (f != nullptr) *f = value;
+    return f != nullptr;
 }
 
 PlanOverride& plan_override() {
@@ -375,6 +381,12 @@ int rgn_plan_override(const char* key, int value) {
     PlanOverride& o = plan_override();
     if (key == nullptr) { o = PlanOverride{-1, -1, -1, -1, -1, -1, -1, -1}; return 0; }
     return plan_set(o, key, value) ? 0 : fail(RGN_E_BADARG, "plan_override: unknown key");
+}
+int rgn_plan_override_get(const char* key, int* value) {
+    int* f = key != nullptr ? plan_field(plan_override(), key) : nullptr;
+    if (f == nullptr || value == nullptr) return fail(RGN_E_BADARG, "plan_override_get: unknown key");
+    *value = *f;
+    return 0;
 }
 const char* rgn_last_error(void) { return g_err; }
 

@@ -212,11 +212,16 @@ rgn_qkv_epilogue epi(const Tensor& x, const Tensor& norm_q, const Tensor& norm_k
     TORCH_CHECK(!(kv_rows.has_value() && kv_rows->defined()) ||
                     (kv_rows->scalar_type() == at::kLong && kv_rows->dim() == 1 && kv_rows->is_contiguous()), "kv_rows: int64 [rows]");
     // extents: the kernel reads cos_q / sin_q at sequence rows [row_base, row_base + M), kv_rows[row_base + m] for every row, and
-    // cos_k / sin_k at the CACHE row of each sequence row (identity rows: the same range; gathered rows: any row of the slab)
+    // cos_k / sin_k at the CACHE row of each sequence row (identity rows: the same range; gathered rows: see below)
     TORCH_CHECK(cos_q.size(0) >= row_base + M, "rotary table of the queries has ", cos_q.size(0), " rows, the problem needs ", row_base + M);
     if (have_rows) {
         TORCH_CHECK(kv_rows->numel() >= row_base + M, "kv_rows has ", kv_rows->numel(), " entries, the problem needs ", row_base + M);
-        TORCH_CHECK(cos_k.size(0) >= skv_pad || cos_k.size(0) >= row_base + M, "rotary table of the keys is shorter than the rows it is read at");
+        // gathered cache rows: the kernel reads cos_k / sin_k at row kv_rows[row_base + m] and writes slab row kv_rows[row_base + m].  The
+        // VALUES are device data and are NOT checked here (that would be a host sync per launch): the caller guarantees
+        // max(kv_rows) < min(cos_k rows, skv_pad).  What can be checked is the necessary condition: the rows are distinct scatter
+        // targets, so the table and the slab must hold at least as many rows as the problem names.
+        TORCH_CHECK(cos_k.size(0) >= row_base + M && skv_pad >= row_base + M, "rotary table of the keys (", cos_k.size(0), " rows) / the slab (",
+                    skv_pad, " rows) cannot hold the ", row_base + M, " distinct cache rows kv_rows names");
     } else {
         TORCH_CHECK(cos_k.size(0) >= row_base + M, "rotary table of the keys has ", cos_k.size(0), " rows, the problem needs ", row_base + M);
         TORCH_CHECK(row_base + M <= skv_pad, "identity cache rows [", row_base, ", ", row_base + M, ") exceed the slab's ", skv_pad, " rows");

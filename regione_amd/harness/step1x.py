@@ -100,9 +100,15 @@ class Step1XEditPipeline(H.FluxKontextPipeline):
     def _batched_inputs(self, x, prompt_embeds, negative_prompt_embeds):
         """The B = 2 inputs of the reference's batched CFG (Step1XEdit/inplace.py:381-385): `cat((x, x))` as a copy-free repeat, the
         two prompt embeddings stacked once per (cond, uncond) pair of tensors (device-to-device copies, not once per step)."""
-        key = (prompt_embeds.data_ptr(), negative_prompt_embeds.data_ptr(), prompt_embeds._version, negative_prompt_embeds._version)
-        if getattr(self, "_pe_key", None) != key:
-            self._pe_key, self._pe = key, ops.cat_rows((prompt_embeds, negative_prompt_embeds), dim=0)
+        # keyed on the tensors THEMSELVES (held, compared by identity) + their versions and shapes: an address key would be recycled by the
+        # caching allocator for the next call's same-shaped embeddings and serve the previous prompt's conditioning (advisor, round 5)
+        def ver(t):
+            return None if t.is_inference() else t._version
+        src = getattr(self, "_pe_src", None)
+        key = (ver(prompt_embeds), ver(negative_prompt_embeds), tuple(prompt_embeds.shape), tuple(negative_prompt_embeds.shape))
+        if src is None or src[0] is not prompt_embeds or src[1] is not negative_prompt_embeds or self._pe_key != key:
+            self._pe_src, self._pe_key = (prompt_embeds, negative_prompt_embeds), key
+            self._pe = ops.cat_rows((prompt_embeds, negative_prompt_embeds), dim=0)
         return H.repeat_batch(x, 2), self._pe
 
     @torch.no_grad()

@@ -313,6 +313,11 @@ def qkv_epilogue(*, wq, wk, rope_q, rope_k, k_slab, vt_slab, H: int, k_col: int,
         if kv_rows is not None:
             if kv_rows.numel() < need:
                 raise _lib.RegionEHipError(f"kv_rows has {kv_rows.numel()} entries, the problem needs {need}")
+            # the VALUES of kv_rows are device data, unchecked (no host sync per launch): the caller guarantees max(kv_rows) <
+            # min(rope_k rows, skv_pad); checked is the necessary condition (distinct scatter targets need that many rows)
+            if rope_k[0].shape[0] < need or skv_pad < need:
+                raise _lib.RegionEHipError(f"key rotary table ({rope_k[0].shape[0]} rows) / slab ({skv_pad} rows) cannot hold the {need} "
+                                           "distinct cache rows kv_rows names")
         elif rope_k[0].shape[0] < need or need > skv_pad:
             raise _lib.RegionEHipError(f"identity cache rows [{row_base}, {need}) exceed the key rotary table / the slab's {skv_pad} rows")
     e = _lib.QkvEpilogue(_p(wq), _p(wk), _p(rope_q[0]), _p(rope_q[1]), _p(rope_k[0]), _p(rope_k[1]), _p(kv_rows),

@@ -23,8 +23,6 @@ except Exception as _e:          # noqa: BLE001 - reported, not fatal: test_capi
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_long: MI355X parity cases at full dimensions that cost 35-50 s of CPU oracle each; NOT part of "
-                                       "`-m gpu` (kept under 300 s) - run with -m gpu_long, log committed under profiles/")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -33,7 +31,7 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="needs a HIP GPU (torch.cuda.is_available() is False)")
     for item in items:
-        if "gpu" in item.keywords or "gpu_long" in item.keywords:
+        if "gpu" in item.keywords:
             item.add_marker(skip)
 
 

@@ -92,6 +92,17 @@ def test_abi_stamp_and_plan_override_hook():
     assert h.rgn_plan_override(None, 0) == 0
     with _lib.plan_override(gemm_pieces=1):
         pass
+    # a scoped override restores what it found (advisor round 5): nested blocks keep the outer value
+    def get(k):
+        v = C.c_int(-7)
+        assert h.rgn_plan_override_get(k.encode(), C.byref(v)) == 0
+        return v.value
+    with _lib.plan_override(gemm_pieces=3, attn_split=0):
+        with _lib.plan_override(gemm_pieces=5):
+            assert get("gemm_pieces") == 5 and get("attn_split") == 0
+        assert get("gemm_pieces") == 3 and get("attn_split") == 0
+    assert get("gemm_pieces") == -1 and get("attn_split") == -1
+    assert h.rgn_plan_override_get(b"no_such_knob", C.byref(C.c_int())) < 0
     with pytest.raises(_lib.RegionEHipError):
         with _lib.plan_override(no_such_knob=1):
             pass

@@ -12,7 +12,7 @@ import torch
 from oracle import regione_oracle as O
 from regione_amd import synth
 
-pytestmark = []          # per test: `gpu`, or `gpu_long` for the bf16 twin of configs[4] (the config itself is fp8 weights)
+pytestmark = []          # per test (every case is `gpu`: round 6 folded the round-5 `gpu_long` set back into the driver-run suite)
 
 
 def _ids_partition_ok(M, h, w, box):
@@ -68,7 +68,7 @@ def test_config3_flux_1024_true_cfg6_full_size(golden):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("weights,depth", [pytest.param("bf16", None, marks=pytest.mark.gpu_long), pytest.param("fp8", None, marks=pytest.mark.gpu_long),
+@pytest.mark.parametrize("weights,depth", [pytest.param("bf16", None, marks=pytest.mark.gpu), pytest.param("fp8", None, marks=pytest.mark.gpu),
                                            pytest.param("fp8", (2, 4), marks=pytest.mark.gpu)])
 def test_config4_step1x_v1p2_2048_50_steps(golden, weights, depth):
     """L = L_c = 16384 (S = 33280 / 33152 rows per branch), 50 denoising steps, tagged sequential CFG 6.0 with text
@@ -80,7 +80,7 @@ def test_config4_step1x_v1p2_2048_50_steps(golden, weights, depth):
     from regione_amd.tool.RegionE import resample_gamma
     from tools.run_configs import weights_stream, make_box
     dev = torch.device("cuda", 0)
-    # depth None = the trunk's 19 + 38 blocks (one edit = 36 s of GPU time: -m gpu_long, and tools/run_configs.py for the timing in
+    # depth None = the trunk's 19 + 38 blocks (one edit = 36 s of GPU time; tools/run_configs.py for the timing in
     # profiles/); (2, 4) = the same widths, sequence lengths, 50-step plan and two 2 x L caches on a 6-block trunk for the -m gpu suite -
     # every property checked below is independent of the depth
     cfg = synth.FluxConfig(guidance_embeds=False) if depth is None else synth.FluxConfig(guidance_embeds=False, n_double=depth[0], n_single=depth[1])

@@ -19,7 +19,7 @@ import torch
 from oracle import regione_oracle as O
 from regione_amd import synth
 
-# FLUX (the headline family) runs under -m gpu; the Qwen and Step1X twins (47 / 34 s of CPU oracle) under -m gpu_long
+# FLUX (the headline family) and the Qwen / Step1X twins (47 / 34 s of CPU oracle) all run under -m gpu
 
 
 def _rel(a, b):
@@ -196,7 +196,7 @@ def _compare_branch_caches(label, procs, prefixes, doubles, caches, tag, wts, he
     return kept
 
 
-@pytest.mark.gpu_long
+@pytest.mark.gpu
 def test_qwen_full_dims_double_block_two_tagged_caches_full_store_then_region_update():
     """Qwen-Image-Edit's block at d = 3072, 24 x 128, joint width 3584, L = L_c = 4096, text lengths 512 (cond) / 384
     (uncond): the reference's forward + tagged two-cache processor (QwenImageEdit/inplace.py:462-571, :737-890) on the HIP
@@ -294,7 +294,7 @@ def test_qwen_full_dims_double_block_two_tagged_caches_full_store_then_region_up
                                ropes[tag], e=e, u=u, stored=stored[tag])
 
 
-@pytest.mark.gpu_long
+@pytest.mark.gpu
 def test_step1x_full_dims_double_and_single_block_batched_cfg_full_store_then_region_update():
     """Step1X-Edit's trunk (FLUX blocks, temb = time_embed + vec_embed(y), no guidance embedder) at d = 3072 with the
     reference's B = 2 batched CFG forward (Step1XEdit/inplace.py:381-399, :460-578): both batch rows of the HIP engine's

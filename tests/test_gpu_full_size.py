@@ -127,6 +127,23 @@ def test_bench_two_ranks_share_the_gpu(extra):
     assert abs(d["value"] - 28 * 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
 
 
+def test_bench_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run (the way the driver starts the 1-GPU
+    line) must not exit with an error: it re-executes itself under torch.distributed.run (127.0.0.1 rendezvous, one process per
+    GPU) and rank 0 prints the one JSON line."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--toy", "--share-gpu", "--dist-backend", "gloo",
+           "--no-cpu-baseline", "--no-vanilla"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and [p["rank"] for p in d["per_rank"]] == [0, 1]
+
+
 @pytest.mark.parametrize("extra", [[], ["--true-cfg", "6.0"]])
 def test_bench_eight_ranks_share_the_gpu(extra):
     """BASELINE configs[3]'s launch shape without an 8-GPU node: EIGHT ranks (gloo, all on cuda:0,

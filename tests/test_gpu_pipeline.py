@@ -228,6 +228,48 @@ def test_step1x_toy_mmdit_vs_oracle():
     assert O.psnr(out, ref) >= 40.0
 
 
+def test_step1x_second_edit_with_another_prompt_does_not_reuse_the_first_prompts_conditioning():
+    """Advisor round 5 (high): the stacked (cond, uncond) prompt embeddings were cached on the pipeline keyed on the inputs' ADDRESSES;
+    the caching allocator hands the same address to the next call's same-shaped embeddings, so a second edit with another prompt ran
+    on the first prompt's conditioning.  Two edits on ONE pipeline object, the first call's embeddings freed in between (so their
+    addresses are recycled), must equal the same edits on fresh pipeline objects."""
+    import gc
+    from regione_amd.harness import step1x as HS
+    cfg = synth.FluxConfig(guidance_embeds=False, **synth.TOY)
+    h = w = 16
+    T = 32
+    wts = synth.make_flux_weights(cfg, seed=5, dtype=torch.bfloat16, w_std=0.05)
+    lat, img, _, _ = synth.make_edit_inputs(h, w, T, cfg, seed=9, dtype=torch.bfloat16)
+
+    def mk():
+        pipe = HS.Step1XEditPipeline(HS.Step1XEditTransformer2DModel(cfg, "cuda").load_state_dict(wts))
+        helper = RegionEHelper(pipe)
+        helper.set_params(threshold=0.1)
+        helper.enable()
+        return pipe
+
+    def edit(pipe, seed):
+        _, _, prompt, y = synth.make_edit_inputs(h, w, T, cfg, seed=seed, dtype=torch.bfloat16)
+        _, _, nprompt, ny = synth.make_edit_inputs(h, w, T, cfg, seed=seed + 100, dtype=torch.bfloat16)
+        pe, npe = prompt.cuda(), nprompt.cuda()
+        ptrs = (pe.data_ptr(), npe.data_ptr())
+        out = pipe(image=img.cuda(), prompt_embeds=pe, pooled_prompt_embeds=y.cuda(), negative_prompt_embeds=npe,
+                   negative_pooled_prompt_embeds=ny.cuda(), height=h * 16, width=w * 16, latents=lat.cuda(), true_cfg_scale=4.0,
+                   return_dict=False)[0].cpu()
+        del pe, npe
+        gc.collect()
+        return out, ptrs
+    shared = mk()
+    a, ptr_a = edit(shared, 21)
+    b, ptr_b = edit(shared, 22)
+    a_fresh, _ = edit(mk(), 21)
+    b_fresh, _ = edit(mk(), 22)
+    assert torch.equal(a, a_fresh)
+    assert torch.equal(b, b_fresh), "the second edit did not see its own prompt"
+    assert not torch.equal(a, b)
+    print("[prompt cache] second call's embeddings reused the first call's addresses:", ptr_a == ptr_b)
+
+
 def test_step1x_v1p2_toy_mmdit_vs_oracle_different_text_lengths():
     """Sequential tagged CFG with T_cond != T_uncond (per-text-length selection rows / RoPE tables and
     per-tag K/V caches, Step1XEditV1P2/inplace.py:833,868) on the HIP engine vs the oracle."""

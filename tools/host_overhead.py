@@ -44,6 +44,30 @@ def main():
                     guidance_scale=2.5, return_dict=False)[0]
     edit(); rec.clear()
     torch.cuda.synchronize()
+    if os.environ.get("PROFILE_FIRST_R"):
+        # cProfile of the FIRST region forward of one edit (the step after the partition: verdict r5 weak #8)
+        import cProfile, pstats, io
+        state = {"done": False}
+        inner = tr.forward
+
+        def prof_fwd(*a, **k):
+            n = k.get("hidden_states", a[0] if a else None).shape[1]
+            if n < h * w and not state["done"]:
+                state["done"] = True
+                torch.cuda.synchronize()
+                pr = cProfile.Profile()
+                pr.enable()
+                r = inner(*a, **k)
+                pr.disable()
+                st = io.StringIO()
+                pstats.Stats(pr, stream=st).sort_stats("cumulative").print_stats(45)
+                print(st.getvalue())
+                return r
+            return inner(*a, **k)
+        tr.forward = prof_fwd
+        edit(); rec.clear()
+        tr.forward = inner
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     edit()
     torch.cuda.synchronize()

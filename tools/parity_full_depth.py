@@ -71,6 +71,18 @@ class reversed_k_linears:
         O._lin = self.orig
 
 
+class FixtureMismatch(RuntimeError):
+    pass
+
+
+def _bits(t):
+    return t.detach().to(torch.bfloat16).cpu().contiguous().view(torch.int16).numpy()
+
+
+def _bf16(a):
+    return torch.from_numpy(a.copy()).view(torch.bfloat16)
+
+
 def rel(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).norm() / b.norm())
@@ -123,11 +135,23 @@ def oracle_kv(w, prefix, cache, heads, T, rope_k, double):
     return O.apply_rope(k, cos, sin)[0], v[0]
 
 
-def _gpu_weights(cfg, seed, w_std=0.02):
+def _gpu_weights(cfg, seed, w_std=0.02, host=True):
     """Weights drawn on the device (12-20 B parameters: seconds instead of minutes) -> (device dict, host copy)."""
     wd = synth.make_flux_weights(cfg, seed=seed, dtype=torch.bfloat16, device="cuda", w_std=w_std)
-    wc = {k: v.cpu() for k, v in wd.items()}
+    wc = {k: v.cpu() for k, v in wd.items()} if host else None
     return wd, wc
+
+
+def weights_fingerprint(wd, n=8):
+    """A fixture's guard against another RNG stream: the bit patterns of the first / last `n` tensors (name order) summed as integers, plus
+    the tensor count and the parameter count."""
+    names = sorted(wd)
+    pick = names[:n] + names[-n:]
+    sums = [int(wd[k].contiguous().view(torch.int16).to(torch.int64).sum().item()) for k in pick]
+    return dict(tensors=len(names), params=int(sum(v.numel() for v in wd.values())), picked=pick, sums=sums)
+
+
+FIXTURE_ROWS_STORE, FIXTURE_ROWS_REGION = 64, 32      # slab rows kept per tensor: 24 heads x 128 x 2 B = 6 KB per row
 
 
 def _box(h, w, r0, r1, c0, c1):
@@ -141,10 +165,18 @@ def _box(h, w, r0, r1, c0, c1):
 # ---------------------------------------------------------------------------------------------------------------------
 # (a) full width, full depth: one FULL store step + one REGION step
 # ---------------------------------------------------------------------------------------------------------------------
-def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
+def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False, save_fixture=None, load_fixture=None):
+    """save_fixture = path: additionally write the ORACLE side of every comparison (both velocities in full, a seeded subset of the
+    last layer's slab rows) + a fingerprint of the device-drawn weights as an .npz; load_fixture = path: take the oracle side from
+    such a file instead of running the oracle (the headline shape costs ~5 min of CPU oracle per pass: tests/test_gpu_full_depth.py
+    runs the HIP side against the committed file in seconds).  With a fixture the slab comparisons run on the stored row subset."""
+    import numpy as np
     from regione_amd import RegionEHelper
     dev = torch.device("cuda", 0)
     t_start = time.time()
+    fx = dict(np.load(load_fixture, allow_pickle=False)) if load_fixture else None
+    if fx is not None:
+        truth = alt = False
     h = w = grid
     L = h * w
     px = grid * 16
@@ -156,7 +188,12 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
         from regione_amd.harness import flux as H
         cfg = synth.FluxConfig() if depth is None else synth.FluxConfig(n_double=depth[0], n_single=depth[1])
     heads = cfg.heads
-    wd, wts = _gpu_weights(cfg, seed=5)
+    wd, wts = _gpu_weights(cfg, seed=5, host=fx is None)
+    fp = weights_fingerprint(wd)
+    if fx is not None:
+        want = json.loads(str(fx["weights_fingerprint"]))
+        if want != fp or [int(v) for v in fx["shape"]] != [grid, T, cfg.n_layers, cfg.d]:
+            raise FixtureMismatch(f"{load_fixture} was generated for other weights / another shape: {want} vs {fp}")
     lat, img, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=9)
     guidance = torch.full([1], 2.5, dtype=torch.float32)
     if qwen:
@@ -225,7 +262,7 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
                 return O.transformer_forward(self.w, ocfg, self.st, self.caches, x.to(self.dtype), prompt.to(self.dtype),
                                              None if qwen else pooled.to(self.dtype), t / 1000, ids, txt_ids,
                                              None if qwen else guidance, fp16_roundtrip=self.rt, rope_full=rope_full)
-    ora = Run(wts, torch.bfloat16, True)
+    ora = Run(wts, torch.bfloat16, True) if fx is None else None
     tru = Run(_Upcast(wts), torch.float32, False) if truth else None
     alt_run = Run(wts, torch.bfloat16, True) if alt else None
 
@@ -242,13 +279,16 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
     out_hip = hip_forward(x_full.to(dev), latent_ids, store)
     timing["hip_full_s"] = time.time() - t0
     t0 = time.time()
-    out_ora = ora.forward(x_full, ids_full, store)
+    out_ora = ora.forward(x_full, ids_full, store) if fx is None else _bf16(fx["vel_full__bf16"])
     timing["oracle_bf16_full_s"] = time.time() - t0
+    keep_fx = {}
+    if save_fixture:
+        keep_fx["vel_full__bf16"] = _bits(out_ora[:, :L])
     t0 = time.time()
     out_tru = tru.forward(x_full, ids_full, store) if truth else None
     timing["oracle_fp32_full_s"] = time.time() - t0
     out_alt = alt_forward(x_full, ids_full, store)
-    assert out_hip.shape == out_ora.shape == (1, 2 * L, 64)
+    assert out_hip.shape == (1, 2 * L, 64) and out_ora.shape[1] in (L, 2 * L)
     print(f"[full-depth parity] {family} timing so far: {timing}", flush=True)
     compare(f"{family} full-step velocity ({cfg.n_layers} blocks, d={cfg.d})", out_hip[:, :L], out_ora[:, :L],
             out_tru[:, :L] if truth else None, rows, alt=out_alt[:, :L] if alt else None)
@@ -265,6 +305,8 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
 
     def kv_triplet():
         k_hip, v_hip = slabs(last_proc, "cond", S, heads)
+        if fx is not None:
+            return (k_hip[:, lo:], None, None), (v_hip[:, lo:], None, None)
         k_o, v_o = oracle_kv(wts, last_prefix, ora.caches[-1], heads, T, rope_k, double)
         if truth:
             k_t, v_t = oracle_kv(_Upcast(wts), last_prefix, tru.caches[-1], heads, T, rope_k, double)
@@ -272,8 +314,17 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
             k_t = v_t = None
         return (k_hip[:, lo:], k_o, k_t), (v_hip[:, lo:], v_o, v_t)
     (kh, ko, kt), (vh, vo, vt) = kv_triplet()
-    compare(f"{family} last-layer K slab after store", kh, ko, kt, rows)
-    compare(f"{family} last-layer V^T slab after store", vh, vo, vt, rows)
+    if fx is not None or save_fixture:      # the stored subset of slab rows (seeded; the same draw on both sides)
+        sub = torch.randperm(S - lo, generator=torch.Generator().manual_seed(11))[:FIXTURE_ROWS_STORE].sort().values
+    if fx is not None:
+        assert torch.equal(sub, torch.from_numpy(fx["rows_store"]))
+        compare(f"{family} last-layer K slab after store ({sub.numel()} fixture rows)", kh[:, sub], _bf16(fx["k_store__bf16"]), None, rows)
+        compare(f"{family} last-layer V^T slab after store ({sub.numel()} fixture rows)", vh[:, sub], _bf16(fx["v_store__bf16"]), None, rows)
+    else:
+        compare(f"{family} last-layer K slab after store", kh, ko, kt, rows)
+        compare(f"{family} last-layer V^T slab after store", vh, vo, vt, rows)
+        if save_fixture:
+            keep_fx.update(rows_store=sub.numpy(), k_store__bf16=_bits(ko[:, sub]), v_store__bf16=_bits(vo[:, sub]))
     k_store, v_store = kh.clone(), vh.clone()
 
     # ---- REGION step: K_e = (grid/2)^2 edited tokens, partial K/V update -----------------------------------------------------
@@ -288,7 +339,7 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
     out_hip = hip_forward(lat_e.to(dev), latent_ids[e], M.warmup_step)
     timing["hip_region_s"] = time.time() - t0
     t0 = time.time()
-    out_ora = ora.forward(lat_e, ids_full[e], M.warmup_step)
+    out_ora = ora.forward(lat_e, ids_full[e], M.warmup_step) if fx is None else _bf16(fx["vel_region__bf16"])
     out_tru = tru.forward(lat_e, ids_full[e], M.warmup_step) if truth else None
     timing["oracle_region_s"] = time.time() - t0
     out_alt = alt_forward(lat_e, ids_full[e], M.warmup_step)
@@ -296,8 +347,23 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
     compare(f"{family} region-step velocity (K_e={e.numel()})", out_hip, out_ora, out_tru, rows, alt=out_alt)
     (kh, ko, kt), (vh, vo, vt) = kv_triplet()
     rw = (T + e) - lo                                            # rewritten image rows (slab row T + id)
-    compare(f"{family} last-layer rewritten K rows", kh[:, rw], ko[:, rw], kt[:, rw] if truth else None, rows)
-    compare(f"{family} last-layer rewritten V rows", vh[:, rw], vo[:, rw], vt[:, rw] if truth else None, rows)
+    if fx is not None or save_fixture:
+        rws = rw[torch.randperm(rw.numel(), generator=torch.Generator().manual_seed(12))[:FIXTURE_ROWS_REGION].sort().values]
+    if fx is not None:
+        assert torch.equal(rws, torch.from_numpy(fx["rows_region"]))
+        compare(f"{family} last-layer rewritten K rows ({rws.numel()} fixture rows)", kh[:, rws], _bf16(fx["k_region__bf16"]), None, rows)
+        compare(f"{family} last-layer rewritten V rows ({rws.numel()} fixture rows)", vh[:, rws], _bf16(fx["v_region__bf16"]), None, rows)
+    else:
+        compare(f"{family} last-layer rewritten K rows", kh[:, rw], ko[:, rw], kt[:, rw] if truth else None, rows)
+        compare(f"{family} last-layer rewritten V rows", vh[:, rw], vo[:, rw], vt[:, rw] if truth else None, rows)
+    if save_fixture:
+        keep_fx.update(vel_region__bf16=_bits(out_ora), rows_region=rws.numpy(), k_region__bf16=_bits(ko[:, rws]), v_region__bf16=_bits(vo[:, rws]),
+                       weights_fingerprint=np.array(json.dumps(fp)), shape=np.array([grid, T, cfg.n_layers, cfg.d]),
+                       generator=np.array("tools/parity_full_depth.py --cases %s_headline --save-fixture (oracle/regione_oracle.py in bf16 on the "
+                                          "CPU of an MI355X box; weights drawn on the device, seed 5)" % family))
+        os.makedirs(os.path.dirname(save_fixture), exist_ok=True)
+        np.savez(save_fixture, **keep_fx)
+        print(f"[full-depth parity] wrote fixture {save_fixture} ({os.path.getsize(save_fixture) / 1e6:.2f} MB)", flush=True)
     keep = torch.cat([T + u, T + L + torch.arange(L)]) - lo      # rows a region step must not touch
     untouched = bool(torch.equal(kh[:, keep], k_store[:, keep]) and torch.equal(vh[:, keep], v_store[:, keep]))
     print(f"[full-depth parity] {family} last-layer untouched cache rows bit-identical: {untouched}", flush=True)
@@ -306,6 +372,7 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False):
     gc.collect()
     torch.cuda.empty_cache()
     return dict(case=f"{family}_full_width", family=family, blocks=cfg.n_layers, d=cfg.d, heads=heads, grid=[h, w], T=T,
+                oracle_side=("fixture " + os.path.relpath(load_fixture, ROOT)) if fx is not None else "run in this process",
                 K_e=int(e.numel()), rows=rows, untouched_rows_bit_identical=untouched, timing_s=timing,
                 wall_s=round(time.time() - t_start, 1))
 
@@ -474,15 +541,17 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity_full_depth.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_parity_full_depth.json"))
     ap.add_argument("--cases", default="flux_loop,qwen_loop,step1x_v1p2_loop,flux_width,qwen_width",
                     help="<family>_loop (d = 512, 28 steps) | <family>_fullloop (d = 3072, 28 steps, 16 x 16 grid) | <family>_width (d = 3072, "
                          "16 x 16 grid, one FULL + one REGION step) | <family>_headline (d = 3072, 64 x 64 grid, T = 512, K_e = 1024: the "
                          "bench's shape, one FULL + one REGION step; ~10 min of CPU oracle)")
     ap.add_argument("--no-truth", action="store_true", help="skip the fp32 oracle run of the full-width cases")
     ap.add_argument("--no-alt", action="store_true", help="skip the reversed-K oracle run of the full-width cases")
+    ap.add_argument("--save-fixture", default=None, help="<family>_headline: write the oracle side as this .npz (tests/golden/headline_<family>.npz)")
     ns = ap.parse_args()
-    report = dict(host_threads=torch.get_num_threads(), cases=[])
+    from regione_amd import build as _build
+    report = dict(host_threads=torch.get_num_threads(), csrc_sha16=_build.csrc_hash(), cases=[])
     for c in ns.cases.split(","):
         fam, kind = c.rsplit("_", 1)
         if kind == "loop":
@@ -490,7 +559,7 @@ def main():
         elif kind == "fullloop":
             r = narrow_loop(fam, width="full")
         elif kind == "headline":
-            r = full_width(fam, grid=64, T=512, truth=False, alt=False)
+            r = full_width(fam, grid=64, T=512, truth=False, alt=False, save_fixture=ns.save_fixture)
             r["case"] = f"{fam}_headline_shape"
         else:
             r = full_width(fam, truth=not ns.no_truth, alt=not ns.no_alt)
