@@ -36,7 +36,7 @@ extern "C" {
  * with, rgn_abi_struct_bytes() = sizeof(rgn_qkv_epilogue) * 1000 + sizeof(rgn_gemm_problem) as the library sees them: a binding
  * compiled against another header (a stale libregione_torch.so next to a rebuilt libregione_hip.so) compares both at load time
  * and refuses to run instead of misreading structs passed by pointer. */
-#define RGN_ABI_VERSION 105
+#define RGN_ABI_VERSION 106
 int rgn_version(void);
 size_t rgn_abi_struct_bytes(void);
 const char* rgn_last_error(void);
@@ -190,6 +190,7 @@ typedef struct rgn_qkv_epilogue {
                                   (fused_kernels.py:80); 0: one rounding, like F.linear on store / plain steps */
 } rgn_qkv_epilogue;
 #define RGN_EPI_QKV 3
+#define RGN_EPI_CONV 4            /* rgn_conv_bf16 only */
 int rgn_gemm_bf16_qkv(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N,
                       int K, int gelu_from_col, const rgn_qkv_epilogue* e, void* workspace, size_t workspace_bytes,
                       void* stream);
@@ -339,6 +340,39 @@ size_t rgn_attention_workspace_bytes(int Sq, int H);
  * workgroups (256 query rows; clear = 4 waves x 128 rows for tiny query sets). */
 int rgn_attention_last_plan(void);
 int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes);
+
+/* ---- f4: VAE decode, the host-side step behind the loop ------------------------------------------------------
+ * Replaces `self.vae.decode(latents, return_dict=False)[0]` (reference FluxKontext/inplace.py:396-402; Step1XEdit / Step1XEditV1P2
+ * the same call) for the [EXT] AutoencoderKL of the public FLUX.1 / Step1X-Edit checkpoints (16 latent channels, block widths
+ * 128-256-512-512, 3 ResNet blocks per up level, one mid-block attention head of width 512, GroupNorm(32, eps 1e-6) + SiLU).
+ * Activation layout of every entry: a ZERO-BORDERED pixel-major image [Hp * Wp, C] bf16, Hp = H + 2, Wp = W + 2, row = y * Wp + x of
+ * the PADDED image, channels contiguous.  The caller allocates >= Wp + 1 rows of readable memory in front of row 0 and behind the
+ * last row (guard rows: a 3 x 3 window reads them for border outputs, which are then written as zeros).
+ *
+ * rgn_conv_bf16: Y = conv(X, Wt) + bias (+ resid), border rows of Y written as ZEROS.  taps = 9: 3 x 3, stride 1, zero padding 1, as an
+ * implicit GEMM on the hand-scheduled MFMA loop (K = 9 Cin in (ky, kx, c) order: inside one kernel row the three taps' channels are
+ * contiguous in this layout, so the A tile of a K step is the plain GEMM's at another byte offset); Wt = [Cout, 3, 3, Cin] (the
+ * checkpoint's [Cout, Cin, 3, 3] permuted once at load), needs ldx == Cin.  taps = 1: 1 x 1 (ResNet shortcut, attention projections),
+ * Wt = [Cout, Cin].  Cin % 64 == 0; resid (or NULL) has Y's layout; fp32 accumulation, one bf16 rounding of acc + bias, one of the
+ * residual sum. */
+int rgn_conv_bf16(const void* X, int ldx, const void* Wt, const void* bias, const void* resid, void* Y, int ldy, int Hp, int Wp,
+                  int Cin, int Cout, int taps, void* stream);
+/* GroupNorm(32 groups) over the valid pixels + optional SiLU: Y = silu((X - mean_g) * rstd_g * gamma + beta), border rows of Y = 0.
+ * C in {128, 256, 512}.  Statistics: per-block fp32 partial sums folded in a fixed order + one double-precision pass (no atomics:
+ * bit-reproducible).  `workspace`: rgn_groupnorm_workspace_bytes() bytes, 16-byte aligned, one per stream. */
+size_t rgn_groupnorm_workspace_bytes(void);
+int rgn_groupnorm_silu(const void* X, void* Y, int Hp, int Wp, int C, const void* gamma, const void* beta, float eps, int silu,
+                       void* workspace, void* stream);
+/* Nearest-neighbour 2 x upsample of a padded image [Hp * Wp, C] into the padded image [(2 Hp - 2) * (2 Wp - 2), C] (border zero). */
+int rgn_upsample2x(const void* X, void* Y, int Hp, int Wp, int C, void* stream);
+/* Mid-block attention = three GEMMs (rgn_gemm_bf16) + this pass: S [Hp * Wp, ld] holds q . k for every (query, key) pixel of the
+ * padded image; in place P = softmax(scale * S) per row over the VALID key columns (border pixels and the padding columns
+ * [Hp * Wp, ld) get probability 0).  ld % 8 == 0, ld <= 24576. */
+int rgn_softmax_rows(void* S, int ld, int Hp, int Wp, float scale, void* stream);
+/* z [Cz, H, W] bf16 (one NCHW image) -> padded pixel-major [Hp * Wp, Cpad], channels [Cz, Cpad) and the border zero; and back:
+ * the first Co channels of a padded image with row stride ld -> [Co, H, W] bf16. */
+int rgn_nchw_to_padded(const void* Z, void* Y, int Cz, int H, int W, int Cpad, void* stream);
+int rgn_padded_to_nchw(const void* X, int ld, void* O, int Co, int H, int W, void* stream);
 
 /* Device properties the host side needs for roofline reporting (no torch types). */
 int rgn_device_info(int* cu_count, int* clock_khz, size_t* hbm_bytes);

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libregione_hip.so")
-SOURCES = ["region.hip", "gemm.hip", "norm.hip", "attn.hip"]
+SOURCES = ["region.hip", "gemm.hip", "norm.hip", "attn.hip", "vae.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # region / norm kernels mirror eager op sequences rounding-for-rounding: a*b+c must NOT contract to fma

@@ -1,0 +1,254 @@
+"""VAE decode on the HIP kernels.
+
+The reference ends every edit with `image = self.vae.decode(latents, return_dict=False)[0]` (FluxKontext/inplace.py:396-402; the
+Step1X-Edit pipelines make the same call) and its latency protocol times the whole `pipe(...)` call (src/FluxKontext/main.py:62-73),
+so the decode is part of the reference's end-to-end edit time.  The module is the [EXT] `AutoencoderKL` decoder of the public
+FLUX.1 / Step1X-Edit checkpoints (diffusers layout: conv_in -> mid block (ResNet, one attention head of width 512, ResNet) ->
+four up levels of three ResNet blocks (512, 512, 256, 128 channels; nearest 2 x upsample + 3 x 3 conv after the first three) ->
+GroupNorm + SiLU + conv_out); nothing of it lives in /root/reference: [EXT], unpinned, checked against an fp32 PyTorch module of the
+same architecture (tests/host_vae.py) instead of the oracle.
+
+`HipVaeDecoder(state_dict, device)` adopts a decoder's parameters (diffusers names, with or without the `decoder.` prefix) once:
+3 x 3 kernels re-laid [Cout, Cin, 3, 3] -> [Cout, 3, 3, Cin] bf16.  `decode(z)` runs ~95 launches, all `rgn::` kernels:
+
+  * every convolution = rgn_conv_bf16: an implicit GEMM on the hand-scheduled 256 x 256 MFMA loop over a zero-bordered, pixel-major
+    activation image (csrc/vae.hip header), bias / ResNet skip / border zeroing in its epilogue;
+  * GroupNorm(32) + SiLU = rgn_groupnorm_silu (statistics pass + apply pass, bit-reproducible);
+  * the mid-block attention = three GEMMs + rgn_softmax_rows;
+  * nearest upsample, NCHW <-> padded pixel-major conversions = row kernels.
+
+No CPU / eager fallback: a missing library raises RegionEHipError like every other op of the package.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+
+_p, _stream = ops._p, ops._stream
+
+
+class PaddedImage:
+    """A zero-bordered pixel-major activation image [Hp * Wp, C] bf16 inside a storage tensor with guard rows on both sides."""
+
+    def __init__(self, H: int, W: int, C: int, device):
+        self.H, self.W, self.C = H, W, C
+        self.Hp, self.Wp = H + 2, W + 2
+        self.rows = self.Hp * self.Wp
+        g = self.Wp + 8
+        self.storage = torch.zeros((self.rows + 2 * g, C), dtype=torch.bfloat16, device=device)
+        self.t = self.storage[g:g + self.rows]
+
+    def ptr(self) -> int:
+        return self.t.data_ptr()
+
+
+class _Pool:
+    """Per-decoder activation buffers, reused across layers and calls (everything runs stream-ordered on one stream)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free: Dict[Tuple[int, int, int], List[PaddedImage]] = {}
+
+    def get(self, H, W, C) -> PaddedImage:
+        lst = self.free.setdefault((H, W, C), [])
+        return lst.pop() if lst else PaddedImage(H, W, C, self.device)
+
+    def put(self, img: PaddedImage):
+        self.free.setdefault((img.H, img.W, img.C), []).append(img)
+
+
+def conv(x: PaddedImage, w: torch.Tensor, bias: Optional[torch.Tensor], out: PaddedImage, taps: int, resid: Optional[PaddedImage] = None,
+         cout: Optional[int] = None):
+    """out = conv(x) + bias (+ resid), border rows zero (rgn_conv_bf16)."""
+    cout = w.shape[0] if cout is None else cout
+    if w.shape[1] != taps * x.C or out.C < cout or (resid is not None and (resid.C != out.C or resid.rows != out.rows)) or out.rows != x.rows:
+        raise _lib.RegionEHipError(f"conv: weight {tuple(w.shape)} for {taps} taps x {x.C} channels -> {out.C}")
+    rc = _lib.lib().rgn_conv_bf16(x.ptr(), x.C, _p(w), _p(bias), None if resid is None else resid.ptr(), out.ptr(), out.C, x.Hp, x.Wp,
+                                  x.C, cout, taps, _stream())
+    _lib.check(rc, "rgn_conv_bf16")
+    return out
+
+
+_gn_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _gn_workspace(device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    if key not in _gn_ws:
+        _gn_ws[key] = torch.empty(_lib.lib().rgn_groupnorm_workspace_bytes() // 4, dtype=torch.float32, device=device)
+    return _gn_ws[key]
+
+
+def groupnorm_silu(x: PaddedImage, gamma: torch.Tensor, beta: torch.Tensor, out: PaddedImage, silu: bool = True, eps: float = 1e-6):
+    ws = _gn_workspace(x.t.device)
+    rc = _lib.lib().rgn_groupnorm_silu(x.ptr(), out.ptr(), x.Hp, x.Wp, x.C, _p(gamma), _p(beta), float(eps), int(silu), _p(ws), _stream())
+    _lib.check(rc, "rgn_groupnorm_silu")
+    return out
+
+
+def upsample2x(x: PaddedImage, out: PaddedImage):
+    assert out.H == 2 * x.H and out.W == 2 * x.W and out.C == x.C
+    _lib.check(_lib.lib().rgn_upsample2x(x.ptr(), out.ptr(), x.Hp, x.Wp, x.C, _stream()), "rgn_upsample2x")
+    return out
+
+
+class HipVaeDecoder:
+    """AutoencoderKL decoder ([EXT] diffusers layout) on libregione_hip.so.  `decode(z)`: z [1, Cz, h, w] -> image [1, 3, 8h, 8w] bf16."""
+
+    def __init__(self, state_dict, device, block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2,
+                 norm_eps: float = 1e-6):
+        self.device = torch.device(device)
+        self.ch = tuple(block_out_channels)
+        self.zc, self.nres, self.eps = latent_channels, layers_per_block + 1, norm_eps
+        sd = {(k[len("decoder."):] if k.startswith("decoder.") else k): v for k, v in state_dict.items()}
+        self._sd = sd
+        self.p: Dict[str, torch.Tensor] = {}
+        top = self.ch[-1]
+        for c in self.ch:
+            if c not in (128, 256, 512):
+                raise _lib.RegionEHipError(f"HipVaeDecoder: block width {c} (the kernels cover 128 / 256 / 512 channels)")
+        self._conv3("conv_in", pad_in=64)
+        for r in (0, 1):
+            self._resnet(f"mid_block.resnets.{r}")
+        a = "mid_block.attentions.0."
+        self._vec(a + "group_norm.weight"); self._vec(a + "group_norm.bias")
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            self.p[a + n + ".weight"] = self._take(a + n + ".weight").reshape(top, top).to(self.device, torch.bfloat16).contiguous()
+            self._vec(a + n + ".bias")
+        cin = top
+        self.levels = []
+        for i, co in enumerate(reversed(self.ch)):
+            for j in range(self.nres):
+                self._resnet(f"up_blocks.{i}.resnets.{j}")
+            up = i < len(self.ch) - 1
+            if up:
+                self._conv3(f"up_blocks.{i}.upsamplers.0.conv")
+            self.levels.append((cin, co, up))
+            cin = co
+        self._vec("conv_norm_out.weight"); self._vec("conv_norm_out.bias")
+        self._conv3("conv_out")
+        unused = [k for k in sd if not k.startswith(("encoder.", "quant_conv", "post_quant_conv"))]
+        if unused:
+            raise _lib.RegionEHipError(f"HipVaeDecoder: state dict entries this decoder does not know: {unused[:6]}")
+        if any(k.startswith("post_quant_conv") for k in sd):
+            raise _lib.RegionEHipError("HipVaeDecoder: post_quant_conv is not part of the FLUX.1 / Step1X-Edit VAE (use_post_quant_conv = False)")
+        del self._sd
+        self.pool = _Pool(self.device)
+        self._attn_buf = {}
+
+    # -- parameter adoption -------------------------------------------------------------------------------------------------------
+    def _take(self, name):
+        if name not in self._sd:
+            raise _lib.RegionEHipError(f"HipVaeDecoder: parameter {name} missing from the state dict")
+        return self._sd.pop(name)
+
+    def _vec(self, name):
+        self.p[name] = self._take(name).to(self.device, torch.bfloat16).contiguous()
+
+    def _conv3(self, prefix, pad_in: Optional[int] = None):
+        w = self._take(prefix + ".weight").to(self.device, torch.float32)          # [Cout, Cin, kh, kw]
+        co, ci, kh, kw = w.shape
+        w = w.permute(0, 2, 3, 1)                                                  # [Cout, kh, kw, Cin]
+        if pad_in is not None and ci < pad_in:
+            w = torch.nn.functional.pad(w, (0, pad_in - ci))
+        self.p[prefix + ".weight"] = w.reshape(co, -1).to(torch.bfloat16).contiguous()
+        self._vec(prefix + ".bias")
+
+    def _resnet(self, prefix):
+        for n in ("norm1", "norm2"):
+            self._vec(f"{prefix}.{n}.weight"); self._vec(f"{prefix}.{n}.bias")
+        self._conv3(prefix + ".conv1"); self._conv3(prefix + ".conv2")
+        if prefix + ".conv_shortcut.weight" in self._sd:
+            self._conv3(prefix + ".conv_shortcut")
+
+    # -- blocks -------------------------------------------------------------------------------------------------------------------
+    def _run_resnet(self, x: PaddedImage, prefix: str, cout: int) -> PaddedImage:
+        P, pool = self.p, self.pool
+        n = groupnorm_silu(x, P[prefix + ".norm1.weight"], P[prefix + ".norm1.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
+        h = conv(n, P[prefix + ".conv1.weight"], P[prefix + ".conv1.bias"], pool.get(x.H, x.W, cout), 9)
+        pool.put(n)
+        n2 = groupnorm_silu(h, P[prefix + ".norm2.weight"], P[prefix + ".norm2.bias"], pool.get(x.H, x.W, cout), eps=self.eps)
+        skip = x
+        if prefix + ".conv_shortcut.weight" in P:
+            skip = conv(x, P[prefix + ".conv_shortcut.weight"], P[prefix + ".conv_shortcut.bias"], pool.get(x.H, x.W, cout), 1)
+        conv(n2, P[prefix + ".conv2.weight"], P[prefix + ".conv2.bias"], h, 9, resid=skip)      # h is not an input of this launch
+        pool.put(n2)
+        if skip is not x:
+            pool.put(skip)
+        pool.put(x)
+        return h
+
+    def _run_attention(self, x: PaddedImage) -> PaddedImage:
+        """One head of width C over every pixel (diffusers `Attention`, residual_connection=True): three GEMMs + a row softmax.  The border
+        pixels of the padded image are masked out as keys by the softmax pass and zeroed as outputs by the last projection's epilogue."""
+        P, pool, a = self.p, self.pool, "mid_block.attentions.0."
+        C, rows = x.C, x.rows
+        ldp = ops.padded(rows, 64)
+        key = (rows, C)
+        if key not in self._attn_buf:
+            self._attn_buf[key] = (torch.zeros((rows, ldp), dtype=torch.bfloat16, device=self.device),       # S / P
+                                   torch.zeros((C, ldp), dtype=torch.bfloat16, device=self.device))          # V^T (padding columns stay 0)
+        S, vt = self._attn_buf[key]
+        n = groupnorm_silu(x, P[a + "group_norm.weight"], P[a + "group_norm.bias"], pool.get(x.H, x.W, C), silu=False, eps=self.eps)
+        q = conv(n, P[a + "to_q.weight"], P[a + "to_q.bias"], pool.get(x.H, x.W, C), 1)
+        k = conv(n, P[a + "to_k.weight"], P[a + "to_k.bias"], pool.get(x.H, x.W, C), 1)
+        ops.gemm(P[a + "to_v.weight"], n.t, None, vt[:, :rows])                  # V^T = W_v X^T; b_v is added behind P V (rows of P sum to 1)
+        ops.gemm(q.t, k.t, None, S[:, :rows])                                     # S = Q K^T
+        _lib.check(_lib.lib().rgn_softmax_rows(_p(S), ldp, x.Hp, x.Wp, 1.0 / math.sqrt(C), _stream()), "rgn_softmax_rows")
+        o = q                                                                     # q is dead: O = P V + b_v
+        ops.gemm(S, vt, P[a + "to_v.bias"], o.t)
+        out = conv(o, P[a + "to_out.0.weight"], P[a + "to_out.0.bias"], k, 1, resid=x)       # k is dead
+        pool.put(n); pool.put(o); pool.put(x)
+        return out
+
+    # -- decode -------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor) -> torch.Tensor:
+        if not z.is_cuda or z.dim() != 4 or z.shape[0] != 1 or z.shape[1] != self.zc:
+            raise _lib.RegionEHipError(f"HipVaeDecoder.decode: one latent image [1, {self.zc}, h, w] on the GPU, got {tuple(z.shape)} on {z.device}")
+        z = z.to(torch.bfloat16).contiguous()
+        h, w = z.shape[2], z.shape[3]
+        P, pool, L = self.p, self.pool, _lib.lib()
+        zin = pool.get(h, w, 64)
+        _lib.check(L.rgn_nchw_to_padded(_p(z), zin.ptr(), self.zc, h, w, 64, _stream()), "rgn_nchw_to_padded")
+        top = self.ch[-1]
+        x = conv(zin, P["conv_in.weight"], P["conv_in.bias"], pool.get(h, w, top), 9)
+        pool.put(zin)
+        x = self._run_resnet(x, "mid_block.resnets.0", top)
+        x = self._run_attention(x)
+        x = self._run_resnet(x, "mid_block.resnets.1", top)
+        for i, (cin, co, up) in enumerate(self.levels):
+            for j in range(self.nres):
+                x = self._run_resnet(x, f"up_blocks.{i}.resnets.{j}", co)
+            if up:
+                u = upsample2x(x, pool.get(2 * x.H, 2 * x.W, x.C))
+                pool.put(x)
+                x = conv(u, P[f"up_blocks.{i}.upsamplers.0.conv.weight"], P[f"up_blocks.{i}.upsamplers.0.conv.bias"],
+                         pool.get(u.H, u.W, u.C), 9)
+                pool.put(u)
+        n = groupnorm_silu(x, P["conv_norm_out.weight"], P["conv_norm_out.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
+        pool.put(x)
+        y = conv(n, P["conv_out.weight"], P["conv_out.bias"], pool.get(n.H, n.W, 8), 9, cout=3)
+        pool.put(n)
+        img = torch.empty((1, 3, y.H, y.W), dtype=torch.bfloat16, device=self.device)
+        _lib.check(L.rgn_padded_to_nchw(y.ptr(), 8, _p(img), 3, y.H, y.W, _stream()), "rgn_padded_to_nchw")
+        pool.put(y)
+        return img
+
+    def flops(self, h: int, w: int) -> float:
+        """Algorithmic FLOPs of one decode of an h x w latent (2 * valid pixels * Cout * taps * Cin per convolution + the attention GEMMs)."""
+        top = self.ch[-1]
+        px = h * w
+        f = 2.0 * px * top * 9 * self.zc
+        res = lambda p, ci, co: 2.0 * p * (9 * ci * co + 9 * co * co + (ci * co if ci != co else 0))
+        f += 2 * res(px, top, top) + 2.0 * px * top * top * 4 + 4.0 * px * px * top
+        for cin, co, up in self.levels:
+            f += res(px, cin, co) + (self.nres - 1) * res(px, co, co)
+            if up:
+                px *= 4
+                f += 2.0 * px * 9 * co * co
+        return f + 2.0 * px * 9 * self.ch[0] * 3

@@ -225,7 +225,17 @@ def rot_wrd():
     return [f"s_add_u32 %{WRD}, %{WRD}, {SLOT}", f"s_cmp_lt_u32 %{WRD}, {W_END}", f"s_cselect_b32 %{WRD}, %{WRD}, {W_SLOT0}"]
 
 
+CONV = False      # emit_v3: the A operand walks a 3 x 3 convolution window (see emit_v3)
+
+
 def adv_a():
+    if CONV:
+        # K runs over (ky, kx, c): inside one kernel row the three taps' channels are CONTIGUOUS in a pixel-major [rows, C] image (pixel
+        # x+1 follows pixel x), so the A offset advances by 128 bytes per K tile as in a plain GEMM; after the 3C/64 tiles of a kernel
+        # row it jumps to the next image row: + cjump bytes.  ctap = K tiles left in the current kernel row, crow = 3C/64.
+        return [f"s_add_u32 %{KOFF}, %{KOFF}, 128", "s_sub_u32 %[ctap], %[ctap], 1", "s_cmp_eq_u32 %[ctap], 0",
+                "s_cselect_b32 %[tj], %[cjump], 0", "s_cselect_b32 %[ctap], %[crow], %[ctap]", f"s_add_u32 %{KOFF}, %{KOFF}, %[tj]",
+                f"s_xor_b32 %{STG}, %{STG}, 0x8000"]
     return [f"s_add_u32 %{KOFF}, %{KOFF}, 128", f"s_xor_b32 %{STG}, %{STG}, 0x8000"]
 
 
@@ -567,6 +577,20 @@ def emit_v2():
     return lines
 
 
+def emit_v3():
+    """The ring variant (emit_v1) as an IMPLICIT-GEMM 3 x 3 convolution over a zero-bordered, pixel-major activation image [rows, C]
+    (row = y * Wp + x of the PADDED image): output row m, tap (ky, kx) reads image row m + (ky - 1) * Wp + (kx - 1) - a constant row
+    shift per tap, so the A tile of a K step is the plain GEMM's A tile at another byte offset.  The kernel passes A - (Wp + 1) rows
+    as the base; K = 9 C in (ky, kx, c) order; extra operands: ctap (sgpr, in/out: K tiles left in the current kernel row), crow
+    (sgpr: 3C/64), cjump (sgpr: (Wp - 3) * C * 2 bytes), tj (sgpr scratch).  Same MFMAs in the same order as emit_v1."""
+    global CONV
+    CONV = True
+    try:
+        return emit_v1()
+    finally:
+        CONV = False
+
+
 def write_macro(f, name, lines):
     n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
     f.write(f"// {name}: {len(lines)} instructions, {n_mfma} MFMAs\n")
@@ -584,6 +608,7 @@ def main():
         write_macro(f, "RGN_GEMM_LOOP4W_ASM", emit_v0())
         write_macro(f, "RGN_GEMM_LOOP4W_RING_ASM", emit_v1())
         write_macro(f, "RGN_GEMM_LOOP4W_W8_ASM", emit_v2())
+        write_macro(f, "RGN_GEMM_LOOP4W_CONV_ASM", emit_v3())
         clob = [f'"a{n}"' for n in range(256)] + [f'"v{n}"' for n in range(FRAG0, 256)] + ['"memory"', '"scc"']
         f.write("#define RGN_GEMM_LOOP4W_CLOBBERS " + ", ".join(clob) + "\n")
     print(f"wrote {os.path.normpath(out)}")
