@@ -40,8 +40,8 @@ PEAK_BF16_TFLOPS = 2500.0          # MI355X dense bf16 MFMA, /opt/skills/guides/
 N_STEPS = 28
 # counter summaries of THIS command under rocprofv3 --pmc (tools/probes/measure_counters.sh); quoted only when their csrc_sha16 is the
 # hash of the kernel sources this process runs (load_stamped)
-PMC_TRAFFIC_FILE = "profiles/r05_pmc_traffic.json"
-PMC_MFMA_FILE = "profiles/r05_pmc_mfma.json"
+PMC_TRAFFIC_FILE = "profiles/r06_pmc_traffic.json"
+PMC_MFMA_FILE = "profiles/r06_pmc_mfma.json"
 PARITY_FILES = ("profiles/r06_parity_headline.json", "profiles/r06_parity_full_depth.json")
 
 
