@@ -354,9 +354,14 @@ int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes);
  * contiguous in this layout, so the A tile of a K step is the plain GEMM's at another byte offset); Wt = [Cout, 3, 3, Cin] (the
  * checkpoint's [Cout, Cin, 3, 3] permuted once at load), needs ldx == Cin.  taps = 1: 1 x 1 (ResNet shortcut, attention projections),
  * Wt = [Cout, Cin].  Cin % 64 == 0; resid (or NULL) has Y's layout; fp32 accumulation, one bf16 rounding of acc + bias, one of the
- * residual sum. */
+ * residual sum.
+ * group > 1 (narrow outputs: Cout = 128, the RGB head): one GEMM row = `group` consecutive pixels, its output row = group x ldy columns, and
+ * Wt is the caller-built block-Toeplitz matrix [group * ldy, 3 * (group + 2) * Cin] (taps = 9; row p * ldy + c holds W[c, ky, kx] at
+ * window pixel p + kx of kernel row ky, zeros elsewhere and in the padding channels) or [group * ldy, group * Cin] (taps = 1, block
+ * diagonal); bias = [group * ldy].  The 256-wide tile is then full: MFMA work (group + 2) / 3 of the ideal instead of 256 / Cout.  Rows of Y
+ * up to group - 1 past the image are written (zeros): the caller's guard rows. */
 int rgn_conv_bf16(const void* X, int ldx, const void* Wt, const void* bias, const void* resid, void* Y, int ldy, int Hp, int Wp,
-                  int Cin, int Cout, int taps, void* stream);
+                  int Cin, int Cout, int taps, int group, void* stream);
 /* GroupNorm(32 groups) over the valid pixels + optional SiLU: Y = silu((X - mean_g) * rstd_g * gamma + beta), border rows of Y = 0.
  * C in {128, 256, 512}.  Statistics: per-block fp32 partial sums folded in a fixed order + one double-precision pass (no atomics:
  * bit-reproducible).  `workspace`: rgn_groupnorm_workspace_bytes() bytes, 16-byte aligned, one per stream. */

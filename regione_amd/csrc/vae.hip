@@ -52,17 +52,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const uint16_t* __restric
     }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, double count, float eps,
-                                                         float* __restrict__ stats) {
-    // thread t: group t >> 1, quantity t & 1; both quantities of a group meet through a shuffle
-    const int t = threadIdx.x;
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, double count, float eps,
+                                                           float* __restrict__ stats) {
+    // thread: quantity t = tid & 63 (group t >> 1, sum / sum of squares t & 1), slice tid >> 6 of the blocks; 16 slices folded in a
+    // fixed order in double precision (a single 64-thread block walking 1024 partials took 200 us: 30 such launches per decode)
+    const int t = threadIdx.x & 63, part = threadIdx.x >> 6;
     double acc = 0.0;
-    for (int b = 0; b < nblocks; ++b) acc += (double)partial[(size_t)b * 64 + t];
-    const double other = __shfl_xor(acc, 1, 64);
-    if ((t & 1) == 0) {
-        const double mean = acc / count, var = other / count - mean * mean;
-        stats[t] = (float)mean;
-        stats[t + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+    for (int b = part; b < nblocks; b += 16) acc += (double)partial[(size_t)b * 64 + t];
+    __shared__ double sh[16][64];
+    sh[part][t] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += sh[i][t];
+        const double other = __shfl_xor(tot, 1, 64);
+        if ((t & 1) == 0) {
+            const double mean = tot / count, var = other / count - mean * mean;
+            stats[t] = (float)mean;
+            stats[t + 1] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)eps));
+        }
     }
 }
 
@@ -231,7 +240,7 @@ int rgn_groupnorm_silu(const void* X, void* Y, int Hp, int Wp, int C, const void
     float* stats = partial + (size_t)1024 * 64;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nb), dim3(256), 0, st, (const uint16_t*)X, rows, C, partial);
     const double count = (double)(Hp - 2) * (Wp - 2) * (C / 32);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(64), 0, st, partial, nb, count, eps, stats);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, count, eps, stats);
     const int nb2 = grid_for((size_t)rows, rpb * 4, 4096);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nb2), dim3(256), 0, st, (const uint16_t*)X, (uint16_t*)Y, Hp, Wp, C, stats,
                        (const uint16_t*)gamma, (const uint16_t*)beta, silu);

@@ -38,7 +38,7 @@ class PaddedImage:
         self.H, self.W, self.C = H, W, C
         self.Hp, self.Wp = H + 2, W + 2
         self.rows = self.Hp * self.Wp
-        g = self.Wp + 8
+        g = self.Wp + 72                     # guard rows: a window reads up to Wp + 1 + group rows outside the image, pixel groups write group - 1
         self.storage = torch.zeros((self.rows + 2 * g, C), dtype=torch.bfloat16, device=device)
         self.t = self.storage[g:g + self.rows]
 
@@ -61,14 +61,38 @@ class _Pool:
         self.free.setdefault((img.H, img.W, img.C), []).append(img)
 
 
-def conv(x: PaddedImage, w: torch.Tensor, bias: Optional[torch.Tensor], out: PaddedImage, taps: int, resid: Optional[PaddedImage] = None,
-         cout: Optional[int] = None):
+class ConvWeights:
+    """One convolution's parameters as rgn_conv_bf16 wants them.  `w4`: [Cout, kh, kw, Cin] fp32 (kh = kw = 3 or 1).  group = 1: the matrix
+    [Cout, taps * Cin].  group > 1 (narrow outputs): the block-Toeplitz matrix over a window of group + 2 pixels per kernel row - output row =
+    `group` pixels x `ldy` columns, row p * ldy + c holds w4[c, ky, kx] at window pixel p + kx of kernel row ky (include/regione_hip.h)."""
+
+    def __init__(self, w4: torch.Tensor, bias: torch.Tensor, group: int = 1, ldy: Optional[int] = None):
+        co, kh, kw, ci = w4.shape
+        assert kh == kw and kh in (1, 3)
+        self.taps, self.cout, self.cin, self.group = kh * kw, co, ci, group
+        self.ldy = co if ldy is None else ldy
+        dev = w4.device
+        if group == 1:
+            self.w = w4.reshape(co, -1).to(torch.bfloat16).contiguous()
+            self.b = bias.to(dev, torch.bfloat16).contiguous()
+        else:
+            win = group + 2 if kh == 3 else group
+            t = torch.zeros((group, self.ldy, kh, win, ci), dtype=torch.float32, device=dev)
+            for p in range(group):
+                for kx in range(kw):
+                    t[p, :co, :, p + kx, :] = w4[:, :, kx, :]
+            self.w = t.reshape(group * self.ldy, -1).to(torch.bfloat16).contiguous()
+            b = torch.zeros((group, self.ldy), dtype=torch.float32, device=dev)
+            b[:, :co] = bias.to(dev, torch.float32)
+            self.b = b.reshape(-1).to(torch.bfloat16).contiguous()
+
+
+def conv(x: PaddedImage, cw: ConvWeights, out: PaddedImage, resid: Optional[PaddedImage] = None):
     """out = conv(x) + bias (+ resid), border rows zero (rgn_conv_bf16)."""
-    cout = w.shape[0] if cout is None else cout
-    if w.shape[1] != taps * x.C or out.C < cout or (resid is not None and (resid.C != out.C or resid.rows != out.rows)) or out.rows != x.rows:
-        raise _lib.RegionEHipError(f"conv: weight {tuple(w.shape)} for {taps} taps x {x.C} channels -> {out.C}")
-    rc = _lib.lib().rgn_conv_bf16(x.ptr(), x.C, _p(w), _p(bias), None if resid is None else resid.ptr(), out.ptr(), out.C, x.Hp, x.Wp,
-                                  x.C, cout, taps, _stream())
+    if cw.cin != x.C or out.C != cw.ldy or (resid is not None and (resid.C != out.C or resid.rows != out.rows)) or out.rows != x.rows:
+        raise _lib.RegionEHipError(f"conv: weights for {cw.cin} -> {cw.cout} (row stride {cw.ldy}) on images with {x.C} -> {out.C} channels")
+    rc = _lib.lib().rgn_conv_bf16(x.ptr(), x.C, _p(cw.w), _p(cw.b), None if resid is None else resid.ptr(), out.ptr(), out.C, x.Hp, x.Wp,
+                                  x.C, cw.cout, cw.taps, cw.group, _stream())
     _lib.check(rc, "rgn_conv_bf16")
     return out
 
@@ -100,25 +124,28 @@ class HipVaeDecoder:
     """AutoencoderKL decoder ([EXT] diffusers layout) on libregione_hip.so.  `decode(z)`: z [1, Cz, h, w] -> image [1, 3, 8h, 8w] bf16."""
 
     def __init__(self, state_dict, device, block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2,
-                 norm_eps: float = 1e-6):
+                 norm_eps: float = 1e-6, pixel_groups: bool = True):
         self.device = torch.device(device)
         self.ch = tuple(block_out_channels)
         self.zc, self.nres, self.eps = latent_channels, layers_per_block + 1, norm_eps
         sd = {(k[len("decoder."):] if k.startswith("decoder.") else k): v for k, v in state_dict.items()}
         self._sd = sd
         self.p: Dict[str, torch.Tensor] = {}
+        self.c: Dict[str, ConvWeights] = {}
+        self.pixel_groups = pixel_groups
         top = self.ch[-1]
         for c in self.ch:
             if c not in (128, 256, 512):
                 raise _lib.RegionEHipError(f"HipVaeDecoder: block width {c} (the kernels cover 128 / 256 / 512 channels)")
-        self._conv3("conv_in", pad_in=64)
+        self._conv("conv_in", pad_in=64)
         for r in (0, 1):
             self._resnet(f"mid_block.resnets.{r}")
         a = "mid_block.attentions.0."
         self._vec(a + "group_norm.weight"); self._vec(a + "group_norm.bias")
-        for n in ("to_q", "to_k", "to_v", "to_out.0"):
-            self.p[a + n + ".weight"] = self._take(a + n + ".weight").reshape(top, top).to(self.device, torch.bfloat16).contiguous()
-            self._vec(a + n + ".bias")
+        for n in ("to_q", "to_k", "to_out.0"):
+            self._conv(a + n)
+        self.p[a + "to_v.weight"] = self._take(a + "to_v.weight").reshape(top, top).to(self.device, torch.bfloat16).contiguous()
+        self._vec(a + "to_v.bias")
         cin = top
         self.levels = []
         for i, co in enumerate(reversed(self.ch)):
@@ -126,11 +153,11 @@ class HipVaeDecoder:
                 self._resnet(f"up_blocks.{i}.resnets.{j}")
             up = i < len(self.ch) - 1
             if up:
-                self._conv3(f"up_blocks.{i}.upsamplers.0.conv")
+                self._conv(f"up_blocks.{i}.upsamplers.0.conv")
             self.levels.append((cin, co, up))
             cin = co
         self._vec("conv_norm_out.weight"); self._vec("conv_norm_out.bias")
-        self._conv3("conv_out")
+        self._conv("conv_out", ldy=8)
         unused = [k for k in sd if not k.startswith(("encoder.", "quant_conv", "post_quant_conv"))]
         if unused:
             raise _lib.RegionEHipError(f"HipVaeDecoder: state dict entries this decoder does not know: {unused[:6]}")
@@ -149,33 +176,36 @@ class HipVaeDecoder:
     def _vec(self, name):
         self.p[name] = self._take(name).to(self.device, torch.bfloat16).contiguous()
 
-    def _conv3(self, prefix, pad_in: Optional[int] = None):
-        w = self._take(prefix + ".weight").to(self.device, torch.float32)          # [Cout, Cin, kh, kw]
+    def _conv(self, prefix, pad_in: Optional[int] = None, ldy: Optional[int] = None):
+        w = self._take(prefix + ".weight").to(self.device, torch.float32)          # [Cout, Cin, kh, kw] (or [Cout, Cin]: a Linear)
+        if w.dim() == 2:
+            w = w[:, :, None, None]
         co, ci, kh, kw = w.shape
         w = w.permute(0, 2, 3, 1)                                                  # [Cout, kh, kw, Cin]
         if pad_in is not None and ci < pad_in:
             w = torch.nn.functional.pad(w, (0, pad_in - ci))
-        self.p[prefix + ".weight"] = w.reshape(co, -1).to(torch.bfloat16).contiguous()
-        self._vec(prefix + ".bias")
+        # narrow outputs fill the 256-wide MFMA tile through pixel groups: 128 channels -> 2 pixels per GEMM row, the RGB head -> 8
+        group = 2 if co == 128 else (8 if co <= 8 else 1)
+        self.c[prefix] = ConvWeights(w, self._take(prefix + ".bias"), group=group if self.pixel_groups else 1, ldy=ldy)
 
     def _resnet(self, prefix):
         for n in ("norm1", "norm2"):
             self._vec(f"{prefix}.{n}.weight"); self._vec(f"{prefix}.{n}.bias")
-        self._conv3(prefix + ".conv1"); self._conv3(prefix + ".conv2")
+        self._conv(prefix + ".conv1"); self._conv(prefix + ".conv2")
         if prefix + ".conv_shortcut.weight" in self._sd:
-            self._conv3(prefix + ".conv_shortcut")
+            self._conv(prefix + ".conv_shortcut")
 
     # -- blocks -------------------------------------------------------------------------------------------------------------------
     def _run_resnet(self, x: PaddedImage, prefix: str, cout: int) -> PaddedImage:
-        P, pool = self.p, self.pool
+        P, Cv, pool = self.p, self.c, self.pool
         n = groupnorm_silu(x, P[prefix + ".norm1.weight"], P[prefix + ".norm1.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
-        h = conv(n, P[prefix + ".conv1.weight"], P[prefix + ".conv1.bias"], pool.get(x.H, x.W, cout), 9)
+        h = conv(n, Cv[prefix + ".conv1"], pool.get(x.H, x.W, cout))
         pool.put(n)
         n2 = groupnorm_silu(h, P[prefix + ".norm2.weight"], P[prefix + ".norm2.bias"], pool.get(x.H, x.W, cout), eps=self.eps)
         skip = x
-        if prefix + ".conv_shortcut.weight" in P:
-            skip = conv(x, P[prefix + ".conv_shortcut.weight"], P[prefix + ".conv_shortcut.bias"], pool.get(x.H, x.W, cout), 1)
-        conv(n2, P[prefix + ".conv2.weight"], P[prefix + ".conv2.bias"], h, 9, resid=skip)      # h is not an input of this launch
+        if prefix + ".conv_shortcut" in Cv:
+            skip = conv(x, Cv[prefix + ".conv_shortcut"], pool.get(x.H, x.W, cout))
+        conv(n2, Cv[prefix + ".conv2"], h, resid=skip)      # h is not an input of this launch
         pool.put(n2)
         if skip is not x:
             pool.put(skip)
@@ -185,7 +215,7 @@ class HipVaeDecoder:
     def _run_attention(self, x: PaddedImage) -> PaddedImage:
         """One head of width C over every pixel (diffusers `Attention`, residual_connection=True): three GEMMs + a row softmax.  The border
         pixels of the padded image are masked out as keys by the softmax pass and zeroed as outputs by the last projection's epilogue."""
-        P, pool, a = self.p, self.pool, "mid_block.attentions.0."
+        P, Cv, pool, a = self.p, self.c, self.pool, "mid_block.attentions.0."
         C, rows = x.C, x.rows
         ldp = ops.padded(rows, 64)
         key = (rows, C)
@@ -194,14 +224,14 @@ class HipVaeDecoder:
                                    torch.zeros((C, ldp), dtype=torch.bfloat16, device=self.device))          # V^T (padding columns stay 0)
         S, vt = self._attn_buf[key]
         n = groupnorm_silu(x, P[a + "group_norm.weight"], P[a + "group_norm.bias"], pool.get(x.H, x.W, C), silu=False, eps=self.eps)
-        q = conv(n, P[a + "to_q.weight"], P[a + "to_q.bias"], pool.get(x.H, x.W, C), 1)
-        k = conv(n, P[a + "to_k.weight"], P[a + "to_k.bias"], pool.get(x.H, x.W, C), 1)
+        q = conv(n, Cv[a + "to_q"], pool.get(x.H, x.W, C))
+        k = conv(n, Cv[a + "to_k"], pool.get(x.H, x.W, C))
         ops.gemm(P[a + "to_v.weight"], n.t, None, vt[:, :rows])                  # V^T = W_v X^T; b_v is added behind P V (rows of P sum to 1)
         ops.gemm(q.t, k.t, None, S[:, :rows])                                     # S = Q K^T
         _lib.check(_lib.lib().rgn_softmax_rows(_p(S), ldp, x.Hp, x.Wp, 1.0 / math.sqrt(C), _stream()), "rgn_softmax_rows")
         o = q                                                                     # q is dead: O = P V + b_v
         ops.gemm(S, vt, P[a + "to_v.bias"], o.t)
-        out = conv(o, P[a + "to_out.0.weight"], P[a + "to_out.0.bias"], k, 1, resid=x)       # k is dead
+        out = conv(o, Cv[a + "to_out.0"], k, resid=x)       # k is dead
         pool.put(n); pool.put(o); pool.put(x)
         return out
 
@@ -212,11 +242,11 @@ class HipVaeDecoder:
             raise _lib.RegionEHipError(f"HipVaeDecoder.decode: one latent image [1, {self.zc}, h, w] on the GPU, got {tuple(z.shape)} on {z.device}")
         z = z.to(torch.bfloat16).contiguous()
         h, w = z.shape[2], z.shape[3]
-        P, pool, L = self.p, self.pool, _lib.lib()
+        P, Cv, pool, L = self.p, self.c, self.pool, _lib.lib()
         zin = pool.get(h, w, 64)
         _lib.check(L.rgn_nchw_to_padded(_p(z), zin.ptr(), self.zc, h, w, 64, _stream()), "rgn_nchw_to_padded")
         top = self.ch[-1]
-        x = conv(zin, P["conv_in.weight"], P["conv_in.bias"], pool.get(h, w, top), 9)
+        x = conv(zin, Cv["conv_in"], pool.get(h, w, top))
         pool.put(zin)
         x = self._run_resnet(x, "mid_block.resnets.0", top)
         x = self._run_attention(x)
@@ -227,12 +257,11 @@ class HipVaeDecoder:
             if up:
                 u = upsample2x(x, pool.get(2 * x.H, 2 * x.W, x.C))
                 pool.put(x)
-                x = conv(u, P[f"up_blocks.{i}.upsamplers.0.conv.weight"], P[f"up_blocks.{i}.upsamplers.0.conv.bias"],
-                         pool.get(u.H, u.W, u.C), 9)
+                x = conv(u, Cv[f"up_blocks.{i}.upsamplers.0.conv"], pool.get(u.H, u.W, u.C))
                 pool.put(u)
         n = groupnorm_silu(x, P["conv_norm_out.weight"], P["conv_norm_out.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
         pool.put(x)
-        y = conv(n, P["conv_out.weight"], P["conv_out.bias"], pool.get(n.H, n.W, 8), 9, cout=3)
+        y = conv(n, Cv["conv_out"], pool.get(n.H, n.W, 8))
         pool.put(n)
         img = torch.empty((1, 3, y.H, y.W), dtype=torch.bfloat16, device=self.device)
         _lib.check(L.rgn_padded_to_nchw(y.ptr(), 8, _p(img), 3, y.H, y.W, _stream()), "rgn_padded_to_nchw")

@@ -41,13 +41,17 @@ def _border_is_zero(img):
     return bool((t[0] == 0).all() and (t[-1] == 0).all() and (t[:, 0] == 0).all() and (t[:, -1] == 0).all())
 
 
-@pytest.mark.parametrize("H,W,cin,cout", [(16, 16, 128, 128), (24, 40, 256, 128), (33, 17, 512, 256), (128, 128, 512, 512), (72, 56, 64, 512)])
+@pytest.mark.parametrize("H,W,cin,cout,group", [(16, 16, 128, 128, 1), (16, 16, 128, 128, 2), (24, 40, 256, 128, 2), (33, 17, 512, 256, 1),
+                                                 (128, 128, 512, 512, 1), (72, 56, 64, 512, 1), (40, 72, 128, 3, 8), (25, 31, 128, 3, 8),
+                                                 (127, 129, 128, 128, 2)])
 @pytest.mark.parametrize("resid", [False, True])
 @pytest.mark.parametrize("geometry", [128, 256])
-def test_conv3x3_implicit_gemm_vs_torch(H, W, cin, cout, resid, geometry):
+def test_conv3x3_implicit_gemm_vs_torch(H, W, cin, cout, group, resid, geometry):
     """3 x 3 / stride 1 / zero padding 1 as an implicit GEMM over the zero-bordered image; both geometries (small images run on the
-    128 x 128 tiles, large on the hand-scheduled 256 x 256 loop); ragged sizes; the ResNet skip in the epilogue; zero border kept."""
+    128 x 128 tiles, large on the hand-scheduled 256 x 256 loop); ragged sizes; the ResNet skip in the epilogue; zero border kept;
+    pixel groups (block-Toeplitz weights: 2 pixels per GEMM row for 128 output channels, 8 for the RGB head with row stride 8)."""
     g = torch.Generator().manual_seed(H * 1000 + cin + cout)
+    ldy = 8 if cout == 3 else cout
     x = torch.randn(1, cin, H, W, generator=g)
     w = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / math.sqrt(9 * cin))
     b = torch.randn(cout, generator=g) * 0.1
@@ -56,26 +60,29 @@ def test_conv3x3_implicit_gemm_vs_torch(H, W, cin, cout, resid, geometry):
     ref = torch.nn.functional.conv2d(xb.double(), wb.double(), bb.double(), padding=1).float()
     if resid:
         ref = ref + r.bfloat16().float()
-    xi, out = _padded(x), V.PaddedImage(H, W, cout, "cuda")
-    wt = w.permute(0, 2, 3, 1).reshape(cout, -1).to("cuda", torch.bfloat16).contiguous()
+    xi, out = _padded(x), V.PaddedImage(H, W, ldy, "cuda")
+    cw = V.ConvWeights(w.permute(0, 2, 3, 1).cuda(), b.cuda(), group=group, ldy=ldy)
     with _lib.plan_override(gemm_geometry=geometry):           # both tile geometries on every shape
-        V.conv(xi, wt, b.to("cuda", torch.bfloat16), out, 9, resid=_padded(r) if resid else None)
+        V.conv(xi, cw, out, resid=_padded(r, ldy) if resid else None)
     torch.cuda.synchronize()
     assert _border_is_zero(out)
-    got = _unpadded(out)
+    got = _unpadded(out, cout)
     assert _psnr(got, ref) >= 45.0, _psnr(got, ref)
     assert float((got.float().cpu() - ref).abs().max()) <= 0.05 * float(ref.abs().max())
+    if ldy > cout:                                             # padding channels of the output rows stay zero
+        assert bool((out.t[:, cout:] == 0).all())
 
 
-@pytest.mark.parametrize("H,W,cin,cout", [(16, 16, 512, 256), (128, 128, 256, 128), (40, 24, 512, 512)])
-def test_conv1x1_vs_torch(H, W, cin, cout):
+@pytest.mark.parametrize("H,W,cin,cout,group", [(16, 16, 512, 256, 1), (128, 128, 256, 128, 1), (128, 128, 256, 128, 2), (40, 24, 512, 512, 1),
+                                                 (33, 47, 256, 128, 2)])
+def test_conv1x1_vs_torch(H, W, cin, cout, group):
     g = torch.Generator().manual_seed(7 + cin)
     x = torch.randn(1, cin, H, W, generator=g)
     w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
     b = torch.randn(cout, generator=g) * 0.1
     ref = torch.nn.functional.conv2d(x.bfloat16().double(), w.bfloat16().double()[:, :, None, None], b.bfloat16().double()).float()
     xi, out = _padded(x), V.PaddedImage(H, W, cout, "cuda")
-    V.conv(xi, w.to("cuda", torch.bfloat16).contiguous(), b.to("cuda", torch.bfloat16), out, 1)
+    V.conv(xi, V.ConvWeights(w[:, None, None, :].cuda(), b.cuda(), group=group), out)
     torch.cuda.synchronize()
     assert _border_is_zero(out)
     assert _psnr(_unpadded(out), ref) >= 45.0
@@ -112,16 +119,16 @@ def test_upsample2x_exact():
     assert torch.equal(_unpadded(out).float().cpu(), ref)
 
 
-def _decoder_pair(seed, **kw):
+def _decoder_pair(seed, pixel_groups=True, **kw):
     m = host_vae.seeded(seed, **kw)
-    dec = V.HipVaeDecoder(m.state_dict(), "cuda", **kw)
+    dec = V.HipVaeDecoder(m.state_dict(), "cuda", pixel_groups=pixel_groups, **kw)
     return m, dec
 
 
-@pytest.mark.parametrize("h,w", [(16, 16), (24, 40)])
-def test_decoder_small_latents_vs_fp32_module(h, w):
+@pytest.mark.parametrize("h,w,groups", [(16, 16, True), (24, 40, True), (24, 40, False)])
+def test_decoder_small_latents_vs_fp32_module(h, w, groups):
     """The whole decoder (every block type incl. the mid-block attention and the three upsamples) on small latents."""
-    m, dec = _decoder_pair(3)
+    m, dec = _decoder_pair(3, pixel_groups=groups)
     z = torch.randn(1, 16, h, w, generator=torch.Generator().manual_seed(h))
     with torch.no_grad():
         ref = m.decode(z.bfloat16().float(), return_dict=False)[0]
