@@ -197,6 +197,46 @@ def _loop_extras(kw: dict, sigmas, callback_on_step_end, callback_on_step_end_te
     return kw
 
 
+_NO_HIP_VAE = object()
+
+
+def hip_vae_for(host, dev):
+    """The host's AutoencoderKL decoder adopted onto the HIP kernels (regione_amd/vae.py) - once per host pipeline,
+    kept on it as `_regione_hip_vae`.  None when the host's VAE is not of that layout (Qwen-Image's 3-D causal VAE, a module with a
+    post_quant_conv): the host module then decodes, exactly as in the reference (`self.vae.decode`, FluxKontext/inplace.py:396-402).  A VAE
+    that HAS the layout but cannot be adopted (unknown parameters, other widths) raises instead of silently running the slower module;
+    `pipe._regione_hip_vae = False` before the first call keeps the host module on purpose."""
+    cached = host.__dict__.get("_regione_hip_vae", _NO_HIP_VAE)
+    if cached is False or cached is None:
+        return None
+    if cached is not _NO_HIP_VAE:
+        return cached
+    vae = getattr(host, "vae", None)
+    dec = getattr(vae, "decoder", None)
+    ok = dec is not None and all(hasattr(dec, n) for n in ("conv_in", "mid_block", "up_blocks", "conv_norm_out", "conv_out")) and \
+        getattr(vae, "post_quant_conv", None) is None and hasattr(dec, "state_dict")
+    if not ok:
+        host._regione_hip_vae = None
+        return None
+    from . import vae as V
+    cfg = getattr(vae, "config", None)
+    kw = {}
+    for name in ("block_out_channels", "latent_channels", "layers_per_block"):
+        v = getattr(cfg, name, None) if cfg is not None else None
+        if v is not None:
+            kw[name] = tuple(v) if name == "block_out_channels" else int(v)
+    host._regione_hip_vae = V.HipVaeDecoder(dec.state_dict(), dev, **kw)
+    return host._regione_hip_vae
+
+
+def _decode_image(host, vae, lat, dev):
+    """`vae.decode(lat, return_dict=False)[0]` - on the HIP decoder when the host's VAE is an AutoencoderKL (one image per call)."""
+    hv = hip_vae_for(host, dev)
+    if hv is not None and lat.dim() == 4 and lat.shape[0] == 1:
+        return hv.decode(lat.to(dev))
+    return vae.decode(lat, return_dict=False)[0]
+
+
 class _Clock:
     """Wall-clock of the stages of an edit (end-to-end = encode + loop + decode)."""
 
@@ -281,7 +321,7 @@ def _hosted_flux(host, eng, image=None, prompt=None, prompt_2=None, negative_pro
         lat = host._unpack_latents(latents.to(vae.dtype if hasattr(vae, "dtype") else latents.dtype), height, width,
                                    host.vae_scale_factor)
         lat = lat / vae.config.scaling_factor + vae.config.shift_factor
-        out = host.image_processor.postprocess(vae.decode(lat, return_dict=False)[0], output_type=output_type)
+        out = host.image_processor.postprocess(_decode_image(host, vae, lat, dev), output_type=output_type)
     if hasattr(host, "maybe_free_model_hooks"):
         host.maybe_free_model_hooks()
     clk.mark("decode_s")
@@ -400,7 +440,7 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
         vae = host.vae
         lat = host._unpack_latents(latents.to(getattr(vae, "dtype", latents.dtype)), height, width, host.vae_scale_factor)
         lat = lat / vae.config.scaling_factor + vae.config.shift_factor
-        out = host.image_processor.postprocess(vae.decode(lat, return_dict=False)[0], output_type=output_type)
+        out = host.image_processor.postprocess(_decode_image(host, vae, lat, dev), output_type=output_type)
         out = host._output_process_image(out, img_info)
     if hasattr(host, "maybe_free_model_hooks"):
         host.maybe_free_model_hooks()

@@ -172,3 +172,47 @@ def test_qwen_plus_list_of_condition_images():
     assert proc.caches["cond"][2] == T + L + n1 + L
     assert M.condition_latent.shape[1] == L and 0 < M.edited_ids.shape[1] <= L     # (a random toy trunk edits everything)
     helper.disable()
+
+
+def test_flux_hosted_decode_runs_on_the_hip_vae():
+    """a host whose `vae` is an AutoencoderKL (diffusers layout) gets its decoder adopted onto the HIP kernels
+    at the first hosted call (`pipe._regione_hip_vae`); the image equals the host module's own decode of the same latents (fp32 on the
+    CPU) to >= 40 dB; `pipe._regione_hip_vae = False` keeps the host module; a stand-in VAE without that layout is left alone."""
+    import math
+    import host_vae
+    from regione_amd import vae as V
+
+    class KL(host_vae.AutoencoderKLStandIn):
+        dtype = torch.float32
+        config = HS.Vae.config
+        encode_pixels = HS.Vae.encode_pixels
+        n_decodes = 0
+
+        def decode(self, z, return_dict=True):
+            KL.n_decodes += 1
+            return super().decode(z, return_dict=return_dict)
+
+    torch.manual_seed(11)
+    pipe = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
+    pipe.vae = KL().eval()
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    kw = dict(image=_picture(), prompt="make the square red", guidance_scale=2.5, preferred_resolutions=[(256, 256)])
+    out = pipe(generator=_gen(), output_type="pt", **kw)
+    assert isinstance(pipe._regione_hip_vae, V.HipVaeDecoder) and KL.n_decodes == 0          # the host module did not decode
+    assert tuple(out.images.shape) == (1, 3, 256, 256) and torch.isfinite(out.images.float()).all()
+    lat = pipe(generator=_gen(), output_type="latent", **kw).images
+    z = pipe._unpack_latents(lat.float().cpu(), 256, 256, 8) / KL.config.scaling_factor + KL.config.shift_factor
+    with torch.no_grad():
+        ref = pipe.image_processor.postprocess(super(KL, pipe.vae).decode(z.bfloat16().float(), return_dict=False)[0])
+    mse = float(((out.images.float().cpu() - ref) ** 2).mean())
+    assert 10 * math.log10(1.0 / max(mse, 1e-30)) >= 40.0
+    # opting out keeps the host module
+    pipe._regione_hip_vae = False
+    out2 = pipe(generator=_gen(), output_type="pt", **kw)
+    assert KL.n_decodes == 1 and tuple(out2.images.shape) == (1, 3, 256, 256)
+    helper.disable()
+    # a VAE without the AutoencoderKL layout (the stand-in of the other tests) is not touched
+    pipe2 = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
+    assert A.hip_vae_for(pipe2, torch.device("cuda", 0)) is None and pipe2._regione_hip_vae is None
