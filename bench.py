@@ -655,6 +655,31 @@ def main():
         result["latent_psnr_vs_full_token_random_weights_db"] = {
             "value": O.psnr(out.cpu(), van.cpu()),
             "note": "random weights: not the quality metric (needs a real checkpoint; unmeasurable in this image)"}
+    if rank == 0 and world == 1 and not args.toy and not args.no_vanilla:
+        # SURVEY.md section 8 row f4 / BASELINE.json "end-to-end edit wall-clock": the reference's timing protocol wraps the whole pipe(...) call
+        # (src/FluxKontext/main.py:62-73), whose last stage is `vae.decode` (FluxKontext/inplace.py:396-402).  Untimed leg: the final latents
+        # of the edit above through the HIP decoder (regione_amd/vae.py: [EXT] AutoencoderKL layout, synthetic weights - timing does not
+        # depend on them).  VAE encode + text encoders stay host modules (PyTorch-ROCm eager, tools/f4_host_side.py measured them:
+        # ~56 ms) and are NOT in end_to_end_s.
+        from regione_amd import vae as V
+        dec = V.HipVaeDecoder(V.synthetic_decoder_state_dict(3, device=device), device)
+        z = out[0].view(h_tok, w_tok, 16, 2, 2).permute(2, 0, 3, 1, 4).reshape(1, 16, 2 * h_tok, 2 * w_tok)       # _unpack_latents
+        ms = []
+        for k in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            img = dec.decode(z)
+            torch.cuda.synchronize()
+            ms.append(1e3 * (time.perf_counter() - t0))
+        ms = sorted(ms[1:])
+        d_ms = ms[len(ms) // 2]
+        result["end_to_end"] = {
+            "vae_decode_ms": d_ms, "vae_decode_tflops": dec.flops(2 * h_tok, 2 * w_tok) / d_ms / 1e9,
+            "image": list(img.shape), "end_to_end_s": edit_s + d_ms * 1e-3,
+            "end_to_end_full_token_s": (result["full_token"]["edit_wall_clock_s"] + d_ms * 1e-3) if "full_token" in result else None,
+            "note": "loop + HIP VAE decode (synthetic AutoencoderKL weights); host-side VAE encode / text encoders excluded (eager modules)"}
+        del dec, img
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         # parity with the oracle (torch-CPU bf16 = the reference's dtype path), committed tool reports (tools/parity_full_depth.py; the
         # -m gpu suite re-runs the 16 x 16-grid cases with assertions): round 5 = the HEADLINE shape itself (L = 4096, T = 512, K_e = 1024,

@@ -120,6 +120,58 @@ def upsample2x(x: PaddedImage, out: PaddedImage):
     return out
 
 
+def decoder_param_shapes(block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2):
+    """Parameter names and shapes of the [EXT] AutoencoderKL decoder (diffusers state-dict layout) - for synthetic weights (bench.py,
+    tools): a real checkpoint's `vae.decoder.state_dict()` has exactly these entries."""
+    ch = list(reversed(block_out_channels))
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def conv_(n, co, ci, k):
+        s[n + ".weight"], s[n + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm_(n, c):
+        s[n + ".weight"], s[n + ".bias"] = (c,), (c,)
+
+    def res_(n, ci, co):
+        norm_(n + ".norm1", ci); conv_(n + ".conv1", co, ci, 3); norm_(n + ".norm2", co); conv_(n + ".conv2", co, co, 3)
+        if ci != co:
+            conv_(n + ".conv_shortcut", co, ci, 1)
+    top = ch[0]
+    conv_("conv_in", top, latent_channels, 3)
+    res_("mid_block.resnets.0", top, top); res_("mid_block.resnets.1", top, top)
+    a = "mid_block.attentions.0."
+    norm_(a + "group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[a + n + ".weight"], s[a + n + ".bias"] = (top, top), (top,)
+    cin = top
+    for i, co in enumerate(ch):
+        for j in range(layers_per_block + 1):
+            res_(f"up_blocks.{i}.resnets.{j}", cin if j == 0 else co, co)
+        if i < len(ch) - 1:
+            conv_(f"up_blocks.{i}.upsamplers.0.conv", co, co, 3)
+        cin = co
+    norm_("conv_norm_out", cin)
+    conv_("conv_out", 3, cin, 3)
+    return s
+
+
+def synthetic_decoder_state_dict(seed: int = 0, device="cpu", **kw):
+    """Seeded weights of that layout: convolutions / linears U(-1, 1) / sqrt(fan_in) (PyTorch's default scale), norm weights 1 + 0.2 N(0, 1)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in decoder_param_shapes(**kw).items():
+        if name.endswith(".bias"):
+            sd[name] = 0.1 * torch.randn(shape, generator=g, device=device)
+        elif len(shape) == 1:
+            sd[name] = 1.0 + 0.2 * torch.randn(shape, generator=g, device=device)
+        else:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            sd[name] = (torch.rand(shape, generator=g, device=device) * 2 - 1) / math.sqrt(fan_in)
+    return sd
+
+
 class HipVaeDecoder:
     """AutoencoderKL decoder ([EXT] diffusers layout) on libregione_hip.so.  `decode(z)`: z [1, Cz, h, w] -> image [1, 3, 8h, 8w] bf16."""
 

@@ -210,6 +210,7 @@ def test_flux_hosted_decode_runs_on_the_hip_vae():
     assert 10 * math.log10(1.0 / max(mse, 1e-30)) >= 40.0
     # opting out keeps the host module
     pipe._regione_hip_vae = False
+    pipe.vae.cuda()                                           # the loop's latents live on the GPU: the host module must too
     out2 = pipe(generator=_gen(), output_type="pt", **kw)
     assert KL.n_decodes == 1 and tuple(out2.images.shape) == (1, 3, 256, 256)
     helper.disable()
