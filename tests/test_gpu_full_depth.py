@@ -8,12 +8,9 @@ Rounds 1-3 showed >= 40 dB on 2-4 block trunks and on single full-width blocks; 
     rows: one FULL step with K/V store and one REGION step (K_e = 64, fp16 round trip on the rewritten rows) - velocity and the
     last layer's K / V^T slabs >= 40 dB against the oracle's torch-CPU bf16 run, untouched cache rows bit-identical;
   * full depth at d = 512 through all 28 steps of RegionEHelper against oracle.denoise: plan and edited ids exact, final latents
-    >= 40 dB - or, where the trunk's own arithmetic does not carry 40 dB (Qwen: 60 blocks and a CFG combine that amplifies
-    every difference 7x), no further from the oracle than the oracle's OWN run with every Linear summed in the opposite order
-    along K is (same products, another fp32 accumulation order: the reference arithmetic's run-to-run spread; measured
-    39.8 dB for both on MI355X, profiles/r04_parity_full_depth.json).
+    >= 40 dB for every family (trunk statistics calibrated to a checkpoint's regime, see the test's docstring).
 
-Tolerance: 40 dB = BASELINE.json north_star "PSNR >= 40 dB vs reference latents"; 2 dB of slack on the spread yardstick.
+Tolerance: 40 dB = BASELINE.json north_star "PSNR >= 40 dB vs reference latents".
 """
 import os
 import sys
@@ -41,25 +38,17 @@ def test_full_depth_full_width_full_store_then_region_step_vs_oracle(family):
 @pytest.mark.parametrize("family", [pytest.param("flux", marks=pytest.mark.gpu), pytest.param("qwen", marks=pytest.mark.gpu),
                                     pytest.param("step1x_v1p2", marks=pytest.mark.gpu)])
 def test_full_depth_trunk_28_steps_vs_oracle_denoise(family):
-    """FLUX and Step1X-Edit v1p2: the north star's 40 dB, hard.  Qwen is the ONE explicit exception (advisor, round 4): 60 blocks and
-    a norm-preserving CFG combine `neg + 4 (pos - neg)` put the oracle's own re-ordered run 39.9 dB from itself, so the bar for
-    that family is "no further from the oracle than 2 dB below the oracle's own spread" AND >= 38 dB absolute; round 5 attributes
-    the gap per branch (profiles/r05_parity_qwen_branches.json: both branch velocities >= 40 dB, the combine amplifies)."""
-    import json
+    """All three families: the north star's 40 dB, hard, on a trunk with checkpoint-like statistics (round 6: AdaLN gates / scales of std 0.1,
+    RMSNorm weights 1.5 +- 0.3 - tools/parity_full_depth.py CALIBRATED).  Rounds 4-5 ran gate-1 N(0, 1/d) trunks on which Qwen's 60 blocks
+    + norm-preserving CFG combine `neg + 4 (pos - neg)` put even the oracle's OWN re-ordered run 39.8 dB from itself and carried a
+    per-family exception; on the calibrated trunk that spread is 44 dB (profiles/r06_parity_full_depth.json, measured in the same round)
+    and the exception is gone."""
     import parity_full_depth as P
     r = P.narrow_loop(family, alt=False)
-    assert r["blocks"] == (60 if family == "qwen" else 57)
+    assert r["blocks"] == (60 if family == "qwen" else 57) and r["calibrated_statistics"] == P.CALIBRATED
     assert r["hip_plan"] == r["oracle_plan"] and "R" in r["hip_plan"] and "C" in r["hip_plan"]
     assert r["ids_bit_exact"] and 0 < r["hip_K_e"] < 256
-    if family == "qwen":
-        # the oracle's own spread (its reversed-K run vs its plain run) for this exact case is a property of the ORACLE: measured once
-        # by the tool (`python tools/parity_full_depth.py --cases qwen_loop`, a second 11 s oracle pass) and read from the committed report
-        rep = json.load(open(os.path.join(ROOT, "profiles", "r04_parity_full_depth.json")))
-        spread = next(c for c in rep["cases"] if c["case"] == "qwen_narrow_28_steps")["psnr_oracle_reordered_vs_oracle_db"]
-        assert 39.0 <= spread <= 41.0
-        assert r["psnr_final_db"] >= 38.0 and r["psnr_final_db"] >= spread - 2.0, (r["psnr_final_db"], spread)
-    else:
-        assert r["psnr_final_db"] >= 40.0, r["psnr_final_db"]
+    assert r["psnr_final_db"] >= 40.0, r["psnr_final_db"]
     assert torch.isfinite(torch.tensor(r["rel_final"]))
 
 

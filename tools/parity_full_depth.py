@@ -135,9 +135,9 @@ def oracle_kv(w, prefix, cache, heads, T, rope_k, double):
     return O.apply_rope(k, cos, sin)[0], v[0]
 
 
-def _gpu_weights(cfg, seed, w_std=0.02, host=True):
+def _gpu_weights(cfg, seed, w_std=0.02, host=True, **stats):
     """Weights drawn on the device (12-20 B parameters: seconds instead of minutes) -> (device dict, host copy)."""
-    wd = synth.make_flux_weights(cfg, seed=seed, dtype=torch.bfloat16, device="cuda", w_std=w_std)
+    wd = synth.make_flux_weights(cfg, seed=seed, dtype=torch.bfloat16, device="cuda", w_std=w_std, **stats)
     wc = {k: v.cpu() for k, v in wd.items()} if host else None
     return wd, wc
 
@@ -383,7 +383,14 @@ def full_width(family="flux", grid=16, T=64, truth=True, depth=None, alt=False, 
 NARROW = dict(heads=4, head_dim=128, joint_dim=512, pooled_dim=64)
 
 
-def narrow_loop(family="flux", grid=16, T=32, device="cuda", hip=True, alt=True, width="narrow"):
+# Statistics of the synthetic trunk (synth.make_flux_weights): AdaLN modulation linears scaled so gates / scales /
+# shifts have std 0.1, RMSNorm weights 1.5 +- 0.3 - a trained checkpoint's regime instead of a gate-1, error-amplifying one.  Measured on
+# the oracle alone (Qwen, 60 blocks, d = 512, 28 steps, CFG 4; its reversed-K run vs its plain run / its bf16 run vs its fp32 run):
+# uncalibrated 39.8 / 25.8 dB; mod 0.2, norms 1.5 +- 0.3: 41.6 / 32.5; mod 0.1, norms 1.5 +- 0.3: 44.2 / 37.4; mod 0.1, norms 1.0 +- 0.1: 46.1 / 38.5
+CALIBRATED = dict(mod_scale=0.1, norm_mean=1.5, norm_std=0.3)
+
+
+def narrow_loop(family="flux", grid=16, T=32, device="cuda", hip=True, alt=True, width="narrow", calibrated=True, truth=False):
     """width = "narrow": d = 512 (4 heads); "full": the trunk's real width (d = 3072, 24 heads) - the whole 28-step loop at full width
     AND depth (round 5; ~1-2 min of CPU oracle per pass for FLUX, twice that for Qwen's two branches)."""
     t_start = time.time()
@@ -392,12 +399,12 @@ def narrow_loop(family="flux", grid=16, T=32, device="cuda", hip=True, alt=True,
     threads = torch.get_num_threads()
     torch.set_num_threads(min(threads, 16 if width == "narrow" else 64))
     try:
-        return _narrow_loop(family, grid, T, device, hip, alt, t_start, width)
+        return _narrow_loop(family, grid, T, device, hip, alt, t_start, width, calibrated, truth)
     finally:
         torch.set_num_threads(threads)
 
 
-def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
+def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow", calibrated=True, truth=False):
     h = w = grid
     L = h * w
     qwen, s1x = family == "qwen", family == "step1x_v1p2"
@@ -412,10 +419,11 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
         cfg = synth.FluxConfig(**dims)
         Tn, scale, thr_cache, fam = None, 1.0, 0.04, "flux"
     w_std = cfg.d ** -0.5
+    stats = CALIBRATED if calibrated else {}
     if width == "narrow":
-        wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=w_std)
+        wts = synth.make_flux_weights(cfg, seed=42, dtype=torch.bfloat16, w_std=w_std, **stats)
     else:               # 12-20 B parameters: drawn on the device (seconds), copied to the host for the oracle
-        wts_dev, wts = _gpu_weights(cfg, seed=42, w_std=w_std)
+        wts_dev, wts = _gpu_weights(cfg, seed=42, w_std=w_std, **stats)
     lat, img0, prompt, pooled = synth.make_edit_inputs(h, w, T, cfg, seed=42, dtype=torch.bfloat16)
     if qwen or s1x:
         _, _, nprompt, npooled = synth.make_edit_inputs(h, w, Tn, cfg, seed=43, dtype=torch.bfloat16)
@@ -427,28 +435,33 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
         ids_full = synth.flux_latent_ids(h, w)
     threshold = 0.5
 
-    def oracle_run(img, trace):
+    def oracle_run(img, trace, fp32=False):
+        """fp32 = the "truth" run: the same (bf16-valued) weights and inputs computed in fp32, no fp16 round trip."""
+        W = _Upcast(wts) if fp32 else wts
+        cv = (lambda t: None if t is None else t.float()) if fp32 else (lambda t: t)
         st = O.RegionState()
         st.set_parameters(28, 6, 2, "16", threshold, thr_cache, True)
 
         def mk(pe, pp, Tt):
             caches = [O.KVCache() for _ in range(cfg.n_layers)]
             rope = O.qwen_rope([(1, h, w), (1, h, w)], Tt) if qwen else None
+            pe, pp = cv(pe), cv(pp)
 
             def model(x, t, ids):
                 st.txt_length = Tt
                 tsd = t.expand(x.shape[0]).to(x.dtype)
                 if qwen:
-                    return O.transformer_forward(wts, ocfg, st, caches, x, pe, None, tsd / 1000, ids, None, None, rope_full=rope)
-                return O.transformer_forward(wts, ocfg, st, caches, x, pe, pp, tsd / 1000, ids, torch.zeros(Tt, 3),
-                                             None if s1x else torch.full([1], 2.5, dtype=torch.float32))
+                    return O.transformer_forward(W, ocfg, st, caches, x, pe, None, tsd / 1000, ids, None, None, rope_full=rope,
+                                                 fp16_roundtrip=not fp32)
+                return O.transformer_forward(W, ocfg, st, caches, x, pe, pp, tsd / 1000, ids, torch.zeros(Tt, 3),
+                                             None if s1x else torch.full([1], 2.5, dtype=torch.float32), fp16_roundtrip=not fp32)
             return model
         with torch.no_grad():
             if qwen or s1x:
-                out = O.denoise(mk(prompt, pooled, T), st, lat, img, ids_full, T, h, w, family=fam, trace=trace,
+                out = O.denoise(mk(prompt, pooled, T), st, cv(lat), cv(img), ids_full, T, h, w, family=fam, trace=trace,
                                 neg_model_fn=mk(nprompt, npooled, Tn), true_cfg_scale=scale)
             else:
-                out = O.denoise(mk(prompt, pooled, T), st, lat, img, ids_full, T, h, w, trace=trace)
+                out = O.denoise(mk(prompt, pooled, T), st, cv(lat), cv(img), ids_full, T, h, w, trace=trace)
         return out, st
 
     # pass 1 (arbitrary condition): the one-step estimate at step warmup-1 -> craft a condition with a compact region
@@ -477,6 +490,17 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
                    psnr_oracle_reordered_vs_oracle_db=round(O.psnr(ref_a, ref), 2), rel_oracle_reordered_vs_oracle=rel(ref_a, ref))
         print(f"[full-depth parity] {family} {cfg.n_layers} blocks d={cfg.d}, 28 steps: oracle with reversed-K linears vs oracle "
               f"{res['psnr_oracle_reordered_vs_oracle_db']:.1f} dB (ids equal: {res['oracle_reordered_ids_equal']})", flush=True)
+    ref_t = None
+    if truth:                               # the fp32 run of the same edit: both bf16 executions' distance to it
+        tr_t = {}
+        ref_t, st_t = oracle_run(img, tr_t, fp32=True)
+        res.update(truth_plan="".join(tr_t["kind"]), truth_ids_equal=bool(torch.equal(st_t.edited_ids, st.edited_ids)),
+                   psnr_oracle_vs_truth_db=round(O.psnr(ref.float(), ref_t), 2), rel_oracle_vs_truth=rel(ref, ref_t))
+        if alt:
+            res.update(psnr_oracle_reordered_vs_truth_db=round(O.psnr(ref_a.float(), ref_t), 2))
+        print(f"[full-depth parity] {family} {cfg.n_layers} blocks d={cfg.d}, 28 steps: oracle bf16 vs its fp32 run "
+              f"{res['psnr_oracle_vs_truth_db']:.1f} dB (rel {res['rel_oracle_vs_truth']:.3f}; ids equal: {res['truth_ids_equal']})", flush=True)
+    res["calibrated_statistics"] = dict(CALIBRATED) if calibrated else None
     if not hip:
         return res
     from regione_amd import RegionEHelper
@@ -511,6 +535,8 @@ def _narrow_loop(family, grid, T, device, hip, alt, t_start, width="narrow"):
     Mg = pipe._regione_manager
     ids_equal = bool(torch.equal(Mg.edited_ids.cpu(), st.edited_ids))
     per_step = [round(O.psnr(a.cpu(), b), 1) if a.shape == b.shape else None for a, b in zip(tr_h["latents"], tr_o["latents"])]
+    if ref_t is not None:
+        res.update(psnr_hip_vs_truth_db=round(O.psnr(out.float(), ref_t), 2), rel_hip_vs_truth=rel(out, ref_t))
     res.update(hip_plan="".join(tr_h["kind"]), ids_bit_exact=ids_equal, hip_K_e=int(Mg.edited_ids.shape[1]),
                psnr_final_db=round(O.psnr(out, ref), 2), rel_final=rel(out, ref), psnr_per_step_db=per_step,
                wall_s=round(time.time() - t_start, 1))
@@ -548,6 +574,7 @@ def main():
                          "bench's shape, one FULL + one REGION step; ~10 min of CPU oracle)")
     ap.add_argument("--no-truth", action="store_true", help="skip the fp32 oracle run of the full-width cases")
     ap.add_argument("--no-alt", action="store_true", help="skip the reversed-K oracle run of the full-width cases")
+    ap.add_argument("--uncalibrated", action="store_true", help="<family>_loop / _fullloop: the round-1..5 statistics (modulation linears unscaled)")
     ap.add_argument("--save-fixture", default=None, help="<family>_headline: write the oracle side as this .npz (tests/golden/headline_<family>.npz)")
     ns = ap.parse_args()
     from regione_amd import build as _build
@@ -555,9 +582,9 @@ def main():
     for c in ns.cases.split(","):
         fam, kind = c.rsplit("_", 1)
         if kind == "loop":
-            r = narrow_loop(fam)
+            r = narrow_loop(fam, truth=not ns.no_truth, calibrated=not ns.uncalibrated)
         elif kind == "fullloop":
-            r = narrow_loop(fam, width="full")
+            r = narrow_loop(fam, width="full", truth=not ns.no_truth, calibrated=not ns.uncalibrated)
         elif kind == "headline":
             r = full_width(fam, grid=64, T=512, truth=False, alt=False, save_fixture=ns.save_fixture)
             r["case"] = f"{fam}_headline_shape"
