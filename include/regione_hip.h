@@ -362,6 +362,13 @@ int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes);
  * up to group - 1 past the image are written (zeros): the caller's guard rows. */
 int rgn_conv_bf16(const void* X, int ldx, const void* Wt, const void* bias, const void* resid, void* Y, int ldy, int Hp, int Wp,
                   int Cin, int Cout, int taps, int group, void* stream);
+/* The encoder's downsampling convolution (VAE encode of the condition image, inside the host's `prepare_latents`, reference call site
+ * FluxKontext/inplace.py:210-226): 3 x 3, stride 2, F.pad(x, (0, 1, 0, 1)) + padding 0.  X = padded image [Hp * Wp, Cin] (even H, W);
+ * GEMM row m = yo * Wp + xo on the INPUT pitch (the A row is image row 2 m + Wp + 1: the same loop with a row stride of two pixels);
+ * out_rows[m] (int64, (Hp - 2) / 2 * Wp entries, device) = the row of Y it is stored to - the caller's table: the padded row of output
+ * pixel (yo, xo) for xo < W / 2, a scratch row for the unused columns of the wide grid.  Wt = [Cout, 3, 3, Cin]; no border test. */
+int rgn_conv_s2_bf16(const void* X, const void* Wt, const void* bias, void* Y, int ldy, int Hp, int Wp, int Cin, int Cout,
+                     const int64_t* out_rows, void* stream);
 /* GroupNorm(32 groups) over the valid pixels + optional SiLU: Y = silu((X - mean_g) * rstd_g * gamma + beta), border rows of Y = 0.
  * C in {128, 256, 512}.  Statistics: per-block fp32 partial sums folded in a fixed order + one double-precision pass (no atomics:
  * bit-reproducible).  `workspace`: rgn_groupnorm_workspace_bytes() bytes, 16-byte aligned, one per stream. */

@@ -109,6 +109,7 @@ SIGNATURES = {
     # f4: VAE decoder (implicit-GEMM convolutions + row kernels, csrc/vae.hip)
     "rgn_conv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_void_p],
+    "rgn_conv_s2_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "rgn_groupnorm_workspace_bytes": [],
     "rgn_groupnorm_silu": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p],
     "rgn_upsample2x": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],

@@ -229,6 +229,65 @@ def hip_vae_for(host, dev):
     return host._regione_hip_vae
 
 
+def hip_vae_encoder_for(host, dev):
+    """The host's AutoencoderKL ENCODER on the HIP kernels (regione_amd/vae.py HipVaeEncoder), adopted once per host pipeline
+    (`_regione_hip_vae_encoder`); None when the VAE has no such encoder, carries a quant_conv, or `pipe._regione_hip_vae = False`."""
+    if host.__dict__.get("_regione_hip_vae", _NO_HIP_VAE) is False:
+        return None
+    cached = host.__dict__.get("_regione_hip_vae_encoder", _NO_HIP_VAE)
+    if cached is not _NO_HIP_VAE:
+        return cached
+    vae = getattr(host, "vae", None)
+    enc = getattr(vae, "encoder", None)
+    ok = enc is not None and all(hasattr(enc, n) for n in ("conv_in", "down_blocks", "mid_block", "conv_norm_out", "conv_out")) and \
+        getattr(vae, "quant_conv", None) is None and hasattr(enc, "state_dict")
+    if not ok:
+        host._regione_hip_vae_encoder = None
+        return None
+    from . import vae as V
+    cfg = getattr(vae, "config", None)
+    kw = {}
+    for name in ("block_out_channels", "latent_channels", "layers_per_block"):
+        v = getattr(cfg, name, None) if cfg is not None else None
+        if v is not None:
+            kw[name] = tuple(v) if name == "block_out_channels" else int(v)
+    host._regione_hip_vae_encoder = V.HipVaeEncoder(enc.state_dict(), dev, **kw)
+    return host._regione_hip_vae_encoder
+
+
+class _hip_vae_encode:
+    """`with _hip_vae_encode(host, dev): host.prepare_latents(...)` - the host's own `prepare_latents` (resize, `_encode_vae_image`,
+    `retrieve_latents`, shift / scale, packing: its code, untouched) runs with `vae.encode` answered by the HIP encoder for single 4-D
+    images; anything else (batches, 5-D video-style inputs) falls through to the module's own method.  The binding is undone on exit."""
+
+    def __init__(self, host, dev):
+        self.host, self.dev = host, dev
+
+    def __enter__(self):
+        self.enc = hip_vae_encoder_for(self.host, self.dev)
+        if self.enc is None:
+            return self
+        vae, enc, dev = self.host.vae, self.enc, self.dev
+        self.orig = vae.__dict__.get("encode", _NO_HIP_VAE)
+        own = vae.encode
+
+        def encode(x, return_dict=True, **kw):
+            if isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 3 and not kw:
+                out = enc.encode_dist(x.to(dev))
+                return out if return_dict else (out.latent_dist,)
+            return own(x, return_dict=return_dict, **kw)
+        vae.encode = encode
+        return self
+
+    def __exit__(self, *a):
+        if self.enc is not None:
+            if self.orig is _NO_HIP_VAE:
+                del self.host.vae.__dict__["encode"]
+            else:
+                self.host.vae.encode = self.orig
+        return False
+
+
 def _decode_image(host, vae, lat, dev):
     """`vae.decode(lat, return_dict=False)[0]` - on the HIP decoder when the host's VAE is an AutoencoderKL (one image per call)."""
     hv = hip_vae_for(host, dev)
@@ -298,8 +357,9 @@ def _hosted_flux(host, eng, image=None, prompt=None, prompt_2=None, negative_pro
             pooled_prompt_embeds=negative_pooled_prompt_embeds, device=exec_dev, num_images_per_prompt=1,
             max_sequence_length=max_sequence_length, lora_scale=None)
     # 4. latents: the host packs noise and the VAE-encoded condition image (inplace.py:210-226)
-    latents, image_latents, _, _ = host.prepare_latents(image, 1, eng.transformer.cfg_model.in_channels // 4, height, width,
-                                                        prompt_embeds.dtype, exec_dev, generator, latents)
+    with _hip_vae_encode(host, dev):
+        latents, image_latents, _, _ = host.prepare_latents(image, 1, eng.transformer.cfg_model.in_channels // 4, height, width,
+                                                            prompt_embeds.dtype, exec_dev, generator, latents)
     if image_latents is None:
         raise ValueError("FluxKontext editing needs a condition image")
     clk.mark("encode_s")
@@ -412,7 +472,8 @@ def _hosted_step1x(host, eng, image=None, prompt=None, negative_prompt=None, tru
         text, dtype = None, prompt_embeds.dtype
     # 4. latents
     pl = (image, 1, eng.transformer.cfg_model.in_channels // 4, height, width, dtype, exec_dev, generator)
-    latents, image_latents, _, _ = host.prepare_latents(*pl) if v1p2 else host.prepare_latents(*pl, latents)
+    with _hip_vae_encode(host, dev):
+        latents, image_latents, _, _ = host.prepare_latents(*pl) if v1p2 else host.prepare_latents(*pl, latents)
     clk.mark("encode_s")
     # 5.-6. loop on the engine; the host's connector feeds it per computed step
     tr = eng.transformer

@@ -172,57 +172,56 @@ def synthetic_decoder_state_dict(seed: int = 0, device="cpu", **kw):
     return sd
 
 
-class HipVaeDecoder:
-    """AutoencoderKL decoder ([EXT] diffusers layout) on libregione_hip.so.  `decode(z)`: z [1, Cz, h, w] -> image [1, 3, 8h, 8w] bf16."""
+def conv_s2(x: PaddedImage, cw: "ConvWeights", out: PaddedImage, rows_table: torch.Tensor):
+    """The encoder's downsampler: 3 x 3, stride 2, F.pad (0, 1, 0, 1) (rgn_conv_s2_bf16); `rows_table` = downsample_rows(x, out)."""
+    if cw.cin != x.C or out.C != cw.ldy or cw.group != 1 or cw.taps != 9 or out.H * 2 != x.H or out.W * 2 != x.W:
+        raise _lib.RegionEHipError(f"conv_s2: weights for {cw.cin} -> {cw.cout} on {x.H} x {x.W} x {x.C} -> {out.H} x {out.W} x {out.C}")
+    rc = _lib.lib().rgn_conv_s2_bf16(x.ptr(), _p(cw.w), _p(cw.b), out.ptr(), out.C, x.Hp, x.Wp, x.C, cw.cout, _p(rows_table), _stream())
+    _lib.check(rc, "rgn_conv_s2_bf16")
+    return out
 
-    def __init__(self, state_dict, device, block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2,
-                 norm_eps: float = 1e-6, pixel_groups: bool = True):
+
+def downsample_rows(H: int, W: int, device) -> torch.Tensor:
+    """rgn_conv_s2_bf16's row table for an H x W input (padded pitch W + 2): GEMM row m = yo * (W + 2) + xo -> padded row of output pixel
+    (yo, xo) in the (H / 2 + 2) x (W / 2 + 2) image, or - for the unused columns xo >= W / 2 of the wide grid - the first guard row behind
+    the output image (written, never read).  Built once per size (setup, not on the decode / encode path)."""
+    Wp, Ho, Wo = W + 2, H // 2, W // 2
+    m = torch.arange(Ho * Wp, dtype=torch.int64, device=device)
+    yo, xo = m // Wp, m % Wp
+    row = (yo + 1) * (Wo + 2) + xo + 1
+    return torch.where(xo < Wo, row, torch.full_like(row, (Ho + 2) * (Wo + 2))).contiguous()
+
+
+class _KLBase:
+    """Parameter adoption shared by the decoder and the encoder."""
+
+    def _init_params(self, state_dict, device, prefix, pixel_groups):
         self.device = torch.device(device)
-        self.ch = tuple(block_out_channels)
-        self.zc, self.nres, self.eps = latent_channels, layers_per_block + 1, norm_eps
-        sd = {(k[len("decoder."):] if k.startswith("decoder.") else k): v for k, v in state_dict.items()}
-        self._sd = sd
+        self._sd = {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in state_dict.items()}
         self.p: Dict[str, torch.Tensor] = {}
         self.c: Dict[str, ConvWeights] = {}
         self.pixel_groups = pixel_groups
-        top = self.ch[-1]
-        for c in self.ch:
-            if c not in (128, 256, 512):
-                raise _lib.RegionEHipError(f"HipVaeDecoder: block width {c} (the kernels cover 128 / 256 / 512 channels)")
-        self._conv("conv_in", pad_in=64)
-        for r in (0, 1):
-            self._resnet(f"mid_block.resnets.{r}")
-        a = "mid_block.attentions.0."
+        self.pool = _Pool(self.device)
+        self._attn_buf = {}
+
+    def _done(self, what, ignore=()):
+        unused = [k for k in self._sd if not k.startswith(tuple(ignore))]
+        if unused:
+            raise _lib.RegionEHipError(f"{what}: state dict entries it does not know: {unused[:6]}")
+        del self._sd
+
+
+    def _attention(self, a, top):
         self._vec(a + "group_norm.weight"); self._vec(a + "group_norm.bias")
         for n in ("to_q", "to_k", "to_out.0"):
             self._conv(a + n)
         self.p[a + "to_v.weight"] = self._take(a + "to_v.weight").reshape(top, top).to(self.device, torch.bfloat16).contiguous()
         self._vec(a + "to_v.bias")
-        cin = top
-        self.levels = []
-        for i, co in enumerate(reversed(self.ch)):
-            for j in range(self.nres):
-                self._resnet(f"up_blocks.{i}.resnets.{j}")
-            up = i < len(self.ch) - 1
-            if up:
-                self._conv(f"up_blocks.{i}.upsamplers.0.conv")
-            self.levels.append((cin, co, up))
-            cin = co
-        self._vec("conv_norm_out.weight"); self._vec("conv_norm_out.bias")
-        self._conv("conv_out", ldy=8)
-        unused = [k for k in sd if not k.startswith(("encoder.", "quant_conv", "post_quant_conv"))]
-        if unused:
-            raise _lib.RegionEHipError(f"HipVaeDecoder: state dict entries this decoder does not know: {unused[:6]}")
-        if any(k.startswith("post_quant_conv") for k in sd):
-            raise _lib.RegionEHipError("HipVaeDecoder: post_quant_conv is not part of the FLUX.1 / Step1X-Edit VAE (use_post_quant_conv = False)")
-        del self._sd
-        self.pool = _Pool(self.device)
-        self._attn_buf = {}
 
     # -- parameter adoption -------------------------------------------------------------------------------------------------------
     def _take(self, name):
         if name not in self._sd:
-            raise _lib.RegionEHipError(f"HipVaeDecoder: parameter {name} missing from the state dict")
+            raise _lib.RegionEHipError(f"{type(self).__name__}: parameter {name} missing from the state dict")
         return self._sd.pop(name)
 
     def _vec(self, name):
@@ -287,6 +286,39 @@ class HipVaeDecoder:
         pool.put(n); pool.put(o); pool.put(x)
         return out
 
+
+class HipVaeDecoder(_KLBase):
+    """AutoencoderKL decoder ([EXT] diffusers layout) on libregione_hip.so.  `decode(z)`: z [1, Cz, h, w] -> image [1, 3, 8h, 8w] bf16."""
+
+    def __init__(self, state_dict, device, block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2,
+                 norm_eps: float = 1e-6, pixel_groups: bool = True):
+        self.ch = tuple(block_out_channels)
+        self.zc, self.nres, self.eps = latent_channels, layers_per_block + 1, norm_eps
+        self._init_params(state_dict, device, "decoder.", pixel_groups)
+        top = self.ch[-1]
+        for c in self.ch:
+            if c not in (128, 256, 512):
+                raise _lib.RegionEHipError(f"HipVaeDecoder: block width {c} (the kernels cover 128 / 256 / 512 channels)")
+        self._conv("conv_in", pad_in=64)
+        for r in (0, 1):
+            self._resnet(f"mid_block.resnets.{r}")
+        self._attention("mid_block.attentions.0.", top)
+        cin = top
+        self.levels = []
+        for i, co in enumerate(reversed(self.ch)):
+            for j in range(self.nres):
+                self._resnet(f"up_blocks.{i}.resnets.{j}")
+            up = i < len(self.ch) - 1
+            if up:
+                self._conv(f"up_blocks.{i}.upsamplers.0.conv")
+            self.levels.append((cin, co, up))
+            cin = co
+        self._vec("conv_norm_out.weight"); self._vec("conv_norm_out.bias")
+        self._conv("conv_out", ldy=8)
+        if any(k.startswith("post_quant_conv") for k in self._sd):
+            raise _lib.RegionEHipError("HipVaeDecoder: post_quant_conv is not part of the FLUX.1 / Step1X-Edit VAE (use_post_quant_conv = False)")
+        self._done("HipVaeDecoder", ignore=("encoder.", "quant_conv"))
+
     # -- decode -------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, z: torch.Tensor) -> torch.Tensor:
@@ -333,3 +365,115 @@ class HipVaeDecoder:
                 px *= 4
                 f += 2.0 * px * 9 * co * co
         return f + 2.0 * px * 9 * self.ch[0] * 3
+
+
+class LatentDist:
+    """`vae.encode(x).latent_dist` of diffusers' AutoencoderKL (DiagonalGaussianDistribution) over the HIP encoder's moments: what the host's
+    `retrieve_latents(encoder_output, generator, sample_mode)` reads - `.mode()` (FLUX.1-Kontext: sample_mode = "argmax") and `.sample()`."""
+
+    def __init__(self, moments: torch.Tensor):
+        self.mean, logvar = torch.chunk(moments, 2, dim=1)
+        self.logvar = torch.clamp(logvar.float(), -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar).to(moments.dtype)
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None):
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device if generator is None else generator.device,
+                            dtype=torch.float32).to(self.mean.device, self.mean.dtype)
+        return self.mean + self.std * noise
+
+
+class EncoderOutput:
+    def __init__(self, moments):
+        self.latent_dist = LatentDist(moments)
+
+
+class HipVaeEncoder(_KLBase):
+    """AutoencoderKL encoder ([EXT] diffusers layout: conv_in, four down levels of two ResNet blocks (128, 256, 512, 512; a stride-2 3 x 3
+    convolution with F.pad (0, 1, 0, 1) after the first three), the mid block, GroupNorm + SiLU + conv_out to 2 x latent channels; no
+    quant_conv in the FLUX.1 / Step1X-Edit VAE) on libregione_hip.so - the VAE encode of the condition image the host's `prepare_latents`
+    runs before the loop (reference call site FluxKontext/inplace.py:210-226).  `encode(x)`: image [1, 3, H, W] (H, W multiples of 8) ->
+    moments [1, 2 Cz, H / 8, W / 8] bf16; `encode_dist(x)` wraps them as `vae.encode(x)` does (`.latent_dist.mode() / .sample()`)."""
+
+    def __init__(self, state_dict, device, block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2,
+                 norm_eps: float = 1e-6, pixel_groups: bool = True):
+        self.ch = tuple(block_out_channels)
+        self.zc, self.nres, self.eps = latent_channels, layers_per_block, norm_eps
+        self._init_params(state_dict, device, "encoder.", pixel_groups)
+        for c in self.ch:
+            if c not in (128, 256, 512):
+                raise _lib.RegionEHipError(f"HipVaeEncoder: block width {c} (the kernels cover 128 / 256 / 512 channels)")
+        self._conv("conv_in", pad_in=64)
+        cin = self.ch[0]
+        self.levels = []
+        for i, co in enumerate(self.ch):
+            for j in range(self.nres):
+                self._resnet(f"down_blocks.{i}.resnets.{j}")
+            down = i < len(self.ch) - 1
+            if down:
+                pg, self.pixel_groups = self.pixel_groups, False         # the stride-2 launch stores through a row table: no pixel groups
+                self._conv(f"down_blocks.{i}.downsamplers.0.conv")
+                self.pixel_groups = pg
+            self.levels.append((cin, co, down))
+            cin = co
+        top = self.ch[-1]
+        for r in (0, 1):
+            self._resnet(f"mid_block.resnets.{r}")
+        self._attention("mid_block.attentions.0.", top)
+        self._vec("conv_norm_out.weight"); self._vec("conv_norm_out.bias")
+        self._conv("conv_out")
+        if any(k.startswith("quant_conv") for k in self._sd):
+            raise _lib.RegionEHipError("HipVaeEncoder: quant_conv is not part of the FLUX.1 / Step1X-Edit VAE (use_quant_conv = False)")
+        self._done("HipVaeEncoder", ignore=("decoder.", "post_quant_conv"))
+        self._rows = {}
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        if not x.is_cuda or x.dim() != 4 or x.shape[0] != 1 or x.shape[1] != 3 or x.shape[2] % 8 or x.shape[3] % 8:
+            raise _lib.RegionEHipError(f"HipVaeEncoder.encode: one image [1, 3, H, W] on the GPU, H and W multiples of 8; got {tuple(x.shape)} on {x.device}")
+        x = x.to(torch.bfloat16).contiguous()
+        H, W = x.shape[2], x.shape[3]
+        P, Cv, pool, L = self.p, self.c, self.pool, _lib.lib()
+        xin = pool.get(H, W, 64)
+        _lib.check(L.rgn_nchw_to_padded(_p(x), xin.ptr(), 3, H, W, 64, _stream()), "rgn_nchw_to_padded")
+        h = conv(xin, Cv["conv_in"], pool.get(H, W, self.ch[0]))
+        pool.put(xin)
+        for i, (cin, co, down) in enumerate(self.levels):
+            for j in range(self.nres):
+                h = self._run_resnet(h, f"down_blocks.{i}.resnets.{j}", co)
+            if down:
+                key = (h.H, h.W)
+                if key not in self._rows:
+                    self._rows[key] = downsample_rows(h.H, h.W, self.device)
+                d = conv_s2(h, Cv[f"down_blocks.{i}.downsamplers.0.conv"], pool.get(h.H // 2, h.W // 2, h.C), self._rows[key])
+                pool.put(h)
+                h = d
+        top = self.ch[-1]
+        h = self._run_resnet(h, "mid_block.resnets.0", top)
+        h = self._run_attention(h)
+        h = self._run_resnet(h, "mid_block.resnets.1", top)
+        n = groupnorm_silu(h, P["conv_norm_out.weight"], P["conv_norm_out.bias"], pool.get(h.H, h.W, h.C), eps=self.eps)
+        pool.put(h)
+        y = conv(n, Cv["conv_out"], pool.get(n.H, n.W, 2 * self.zc))
+        pool.put(n)
+        out = torch.empty((1, 2 * self.zc, y.H, y.W), dtype=torch.bfloat16, device=self.device)
+        _lib.check(L.rgn_padded_to_nchw(y.ptr(), y.C, _p(out), 2 * self.zc, y.H, y.W, _stream()), "rgn_padded_to_nchw")
+        pool.put(y)
+        return out
+
+    def encode_dist(self, x: torch.Tensor) -> EncoderOutput:
+        return EncoderOutput(self.encode(x))
+
+    def flops(self, H: int, W: int) -> float:
+        px = H * W
+        f = 2.0 * px * self.ch[0] * 9 * 3
+        res = lambda p, ci, co: 2.0 * p * (9 * ci * co + 9 * co * co + (ci * co if ci != co else 0))
+        for cin, co, down in self.levels:
+            f += res(px, cin, co) + (self.nres - 1) * res(px, co, co)
+            if down:
+                px //= 4
+                f += 2.0 * px * 9 * co * co
+        top = self.ch[-1]
+        return f + 2 * res(px, top, top) + 2.0 * px * top * top * 4 + 4.0 * px * px * top + 2.0 * px * 9 * top * 2 * self.zc

@@ -93,12 +93,72 @@ class Decoder(nn.Module):
         return self.conv_out(F.silu(self.conv_norm_out(x)))
 
 
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class DownEncoderBlock2D(nn.Module):
+    def __init__(self, cin, cout, n, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([ResnetBlock2D(cin if j == 0 else cout, cout) for j in range(n)])
+        if down:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout)])
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        return self.downsamplers[0](x) if hasattr(self, "downsamplers") else x
+
+
+class Encoder(nn.Module):
+    """diffusers `Encoder` of the AutoencoderKL: conv_in, DownEncoderBlock2D x 4 (layers_per_block ResNets, stride-2 conv after the first
+    three), the mid block, conv_norm_out -> SiLU -> conv_out to 2 x latent channels (mean | logvar)."""
+
+    def __init__(self, block_out_channels=(128, 256, 512, 512), latent_channels=16, layers_per_block=2):
+        super().__init__()
+        ch = list(block_out_channels)
+        self.conv_in = nn.Conv2d(3, ch[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        cin = ch[0]
+        for i, co in enumerate(ch):
+            self.down_blocks.append(DownEncoderBlock2D(cin, co, layers_per_block, i < len(ch) - 1))
+            cin = co
+        self.mid_block = MidBlock(cin)
+        self.conv_norm_out, self.conv_out = nn.GroupNorm(32, cin, eps=1e-6), nn.Conv2d(cin, 2 * latent_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(F.silu(self.conv_norm_out(self.mid_block(x))))
+
+
 class AutoencoderKLStandIn(nn.Module):
-    """`vae.decode(z, return_dict=False)[0]` of the host pipeline (use_post_quant_conv = False, FLUX.1)."""
+    """`vae.decode(z, return_dict=False)[0]` / `vae.encode(x).latent_dist` of the host pipeline (no quant / post_quant conv: FLUX.1)."""
 
     def __init__(self, **kw):
         super().__init__()
         self.decoder = Decoder(**kw)
+        self.encoder = Encoder(**kw)
+
+    def encode(self, x, return_dict=True):
+        moments = self.encoder(x)
+
+        class Dist:
+            mean = moments[:, : moments.shape[1] // 2]
+
+            def mode(self_):
+                return self_.mean
+
+            def sample(self_, generator=None):
+                lv = moments[:, moments.shape[1] // 2:].clamp(-30, 20)
+                return self_.mean + torch.exp(0.5 * lv) * torch.randn(self_.mean.shape, generator=generator).to(moments)
+        return type("AutoencoderKLOutput", (), {"latent_dist": Dist()})()
 
     def decode(self, z, return_dict=True):
         out = self.decoder(z)

@@ -119,6 +119,69 @@ def test_upsample2x_exact():
     assert torch.equal(_unpadded(out).float().cpu(), ref)
 
 
+@pytest.mark.parametrize("H,W,cin,cout", [(16, 16, 128, 128), (64, 48, 256, 256), (256, 256, 128, 128), (34, 18, 512, 512)])
+@pytest.mark.parametrize("geometry", [128, 256])
+def test_conv_stride2_vs_torch(H, W, cin, cout, geometry):
+    """The encoder's downsampler: F.pad(x, (0, 1, 0, 1)) + Conv2d(3 x 3, stride 2, padding 0) through the wide-grid GEMM + row table."""
+    g = torch.Generator().manual_seed(H + cin)
+    x = torch.randn(1, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.bfloat16().double(), (0, 1, 0, 1)), w.bfloat16().double(), b.bfloat16().double(),
+                                     stride=2).float()
+    xi, out = _padded(x), V.PaddedImage(H // 2, W // 2, cout, "cuda")
+    cw = V.ConvWeights(w.permute(0, 2, 3, 1).cuda(), b.cuda())
+    with _lib.plan_override(gemm_geometry=geometry):
+        V.conv_s2(xi, cw, out, V.downsample_rows(H, W, "cuda"))
+    torch.cuda.synchronize()
+    assert _border_is_zero(out)
+    assert _psnr(_unpadded(out), ref) >= 45.0
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (128, 192), (1024, 1024)])
+def test_encoder_vs_fp32_module(H, W):
+    """VAE encode of the condition image (the host's prepare_latents; FluxKontext/inplace.py:210-226): moments (mean | logvar) of the HIP
+    encoder against the fp32 module, >= 40 dB; at 1024 x 1024 also the time next to the eager bf16 module."""
+    import time
+    m = host_vae.seeded(7)
+    enc = V.HipVaeEncoder(m.state_dict(), "cuda")
+    x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(H)).clamp(-1, 1)
+    mg = m.cuda()
+    with torch.no_grad():
+        ref = mg.encoder(x.bfloat16().float().cuda()).cpu()
+    got = enc.encode(x.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == (1, 32, H // 8, W // 8) and torch.isfinite(got.float()).all()
+    p = _psnr(got, ref)
+    d = enc.encode_dist(x.cuda()).latent_dist
+    assert torch.equal(d.mode(), got[:, :16]) and d.sample(torch.Generator().manual_seed(0)).shape == (1, 16, H // 8, W // 8)
+    msg = f"[vae] encode {H} x {W}: HIP vs fp32 module {p:.1f} dB"
+    if H == 1024:
+        xc = x.cuda()
+        for _ in range(2):
+            enc.encode(xc)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            enc.encode(xc)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        mb = mg.to(torch.bfloat16)
+        with torch.no_grad():
+            for _ in range(2):
+                mb.encoder(xc.bfloat16())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                mb.encoder(xc.bfloat16())
+            torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / 3 * 1e3
+        msg += f"; {ms:.1f} ms ({enc.flops(H, W) / ms / 1e9:.0f} TFLOP/s) vs eager bf16 {eager:.1f} ms"
+        assert ms < 0.5 * eager, (ms, eager)
+    print(msg)
+    assert p >= 40.0, p
+
+
 def _decoder_pair(seed, pixel_groups=True, **kw):
     m = host_vae.seeded(seed, **kw)
     dec = V.HipVaeDecoder(m.state_dict(), "cuda", pixel_groups=pixel_groups, **kw)

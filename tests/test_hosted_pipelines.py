@@ -185,15 +185,27 @@ def test_flux_hosted_decode_runs_on_the_hip_vae():
     class KL(host_vae.AutoencoderKLStandIn):
         dtype = torch.float32
         config = HS.Vae.config
-        encode_pixels = HS.Vae.encode_pixels
-        n_decodes = 0
+        n_decodes = n_encodes = 0
 
         def decode(self, z, return_dict=True):
             KL.n_decodes += 1
             return super().decode(z, return_dict=return_dict)
 
+        def encode(self, x, return_dict=True):
+            KL.n_encodes += 1
+            return super().encode(x.float().to(next(self.parameters()).device), return_dict=return_dict)
+
+    class FluxKontextPipeline(HS.FluxKontextPipeline):          # RegionEHelper dispatches on the class NAME, like the reference
+        def _latents(self, image, dtype, generator, latents):            # diffusers' _encode_vae_image: retrieve_latents(vae.encode(image), "argmax")
+            z = self.vae.encode(image).latent_dist.mode()
+            z = (z - self.vae.config.shift_factor) * self.vae.config.scaling_factor
+            image_latents = self._pack_latents(z.float().cpu()).to(dtype)
+            if latents is None:
+                latents = torch.randn(image_latents.shape, generator=generator).to(dtype)
+            return latents, image_latents
+
     torch.manual_seed(11)
-    pipe = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
+    pipe = FluxKontextPipeline(HS.stub_trunk("flux"))
     pipe.vae = KL().eval()
     helper = RegionEHelper(pipe)
     helper.set_params(threshold=0.5)
@@ -201,6 +213,13 @@ def test_flux_hosted_decode_runs_on_the_hip_vae():
     kw = dict(image=_picture(), prompt="make the square red", guidance_scale=2.5, preferred_resolutions=[(256, 256)])
     out = pipe(generator=_gen(), output_type="pt", **kw)
     assert isinstance(pipe._regione_hip_vae, V.HipVaeDecoder) and KL.n_decodes == 0          # the host module did not decode
+    assert isinstance(pipe._regione_hip_vae_encoder, V.HipVaeEncoder) and KL.n_encodes == 0  # ... nor encode (prepare_latents' vae.encode)
+    assert "encode" not in pipe.vae.__dict__                                                # the binding is undone after prepare_latents
+    # the condition latents the loop saw = the host module's own encode of the same image (fp32 on the CPU) to >= 40 dB
+    with torch.no_grad():
+        zr = host_vae.AutoencoderKLStandIn.encode(pipe.vae, _picture() * 2 - 1).latent_dist.mode()
+    zh = pipe._regione_hip_vae_encoder.encode((_picture() * 2 - 1).cuda())[:, :16].float().cpu()
+    assert 10 * math.log10(float(zr.max() - zr.min()) ** 2 / max(float(((zh - zr) ** 2).mean()), 1e-30)) >= 40.0
     assert tuple(out.images.shape) == (1, 3, 256, 256) and torch.isfinite(out.images.float()).all()
     lat = pipe(generator=_gen(), output_type="latent", **kw).images
     z = pipe._unpack_latents(lat.float().cpu(), 256, 256, 8) / KL.config.scaling_factor + KL.config.shift_factor
@@ -212,7 +231,7 @@ def test_flux_hosted_decode_runs_on_the_hip_vae():
     pipe._regione_hip_vae = False
     pipe.vae.cuda()                                           # the loop's latents live on the GPU: the host module must too
     out2 = pipe(generator=_gen(), output_type="pt", **kw)
-    assert KL.n_decodes == 1 and tuple(out2.images.shape) == (1, 3, 256, 256)
+    assert KL.n_decodes == 1 and KL.n_encodes == 1 and tuple(out2.images.shape) == (1, 3, 256, 256)
     helper.disable()
     # a VAE without the AutoencoderKL layout (the stand-in of the other tests) is not touched
     pipe2 = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
