@@ -659,25 +659,34 @@ def main():
         # SURVEY.md section 8 row f4 / BASELINE.json "end-to-end edit wall-clock": the reference's timing protocol wraps the whole pipe(...) call
         # (src/FluxKontext/main.py:62-73), whose last stage is `vae.decode` (FluxKontext/inplace.py:396-402).  Untimed leg: the final latents
         # of the edit above through the HIP decoder (regione_amd/vae.py: [EXT] AutoencoderKL layout, synthetic weights - timing does not
-        # depend on them).  VAE encode + text encoders stay host modules (PyTorch-ROCm eager, tools/f4_host_side.py measured them:
-        # ~56 ms) and are NOT in end_to_end_s.
+        # depend on them), and a 1024 x 1024 condition image through the HIP encoder (the host's prepare_latents, inplace.py:210-226).
         from regione_amd import vae as V
         dec = V.HipVaeDecoder(V.synthetic_decoder_state_dict(3, device=device), device)
+        enc = V.HipVaeEncoder(V.synthetic_decoder_state_dict(4, device=device, shapes=V.encoder_param_shapes()), device)
         z = out[0].view(h_tok, w_tok, 16, 2, 2).permute(2, 0, 3, 1, 4).reshape(1, 16, 2 * h_tok, 2 * w_tok)       # _unpack_latents
-        ms = []
-        for k in range(6):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            img = dec.decode(z)
-            torch.cuda.synchronize()
-            ms.append(1e3 * (time.perf_counter() - t0))
-        ms = sorted(ms[1:])
-        d_ms = ms[len(ms) // 2]
+        cond_image = (torch.rand(1, 3, args.size, args.size, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(device)
+
+        def med_ms(fn):
+            ms = []
+            for k in range(6):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                r = fn()
+                torch.cuda.synchronize()
+                ms.append(1e3 * (time.perf_counter() - t0))
+            ms = sorted(ms[1:])
+            return ms[len(ms) // 2], r
+        d_ms, img = med_ms(lambda: dec.decode(z))
+        e_ms, mom = med_ms(lambda: enc.encode(cond_image))
+        vae_s = (d_ms + e_ms) * 1e-3
         result["end_to_end"] = {
             "vae_decode_ms": d_ms, "vae_decode_tflops": dec.flops(2 * h_tok, 2 * w_tok) / d_ms / 1e9,
-            "image": list(img.shape), "end_to_end_s": edit_s + d_ms * 1e-3,
-            "end_to_end_full_token_s": (result["full_token"]["edit_wall_clock_s"] + d_ms * 1e-3) if "full_token" in result else None,
-            "note": "loop + HIP VAE decode (synthetic AutoencoderKL weights); host-side VAE encode / text encoders excluded (eager modules)"}
+            "vae_encode_ms": e_ms, "vae_encode_tflops": enc.flops(args.size, args.size) / e_ms / 1e9,
+            "image": list(img.shape), "end_to_end_s": edit_s + vae_s,
+            "end_to_end_full_token_s": (result["full_token"]["edit_wall_clock_s"] + vae_s) if "full_token" in result else None,
+            "note": "VAE encode of the condition image + loop + VAE decode, all on libregione_hip.so (synthetic AutoencoderKL weights); the "
+                    "text encoders (T5-XXL / CLIP-L: ~17 ms eager, tools/f4_host_side.py) are host modules and not included"}
+        del enc, mom
         del dec, img
         torch.cuda.empty_cache()
     if rank == 0 and world == 1:

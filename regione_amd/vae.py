@@ -155,11 +155,45 @@ def decoder_param_shapes(block_out_channels=(128, 256, 512, 512), latent_channel
     return s
 
 
-def synthetic_decoder_state_dict(seed: int = 0, device="cpu", **kw):
-    """Seeded weights of that layout: convolutions / linears U(-1, 1) / sqrt(fan_in) (PyTorch's default scale), norm weights 1 + 0.2 N(0, 1)."""
+def encoder_param_shapes(block_out_channels=(128, 256, 512, 512), latent_channels: int = 16, layers_per_block: int = 2):
+    """The same for the encoder (`vae.encoder.state_dict()`)."""
+    ch = list(block_out_channels)
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def conv_(n, co, ci, k):
+        s[n + ".weight"], s[n + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm_(n, c):
+        s[n + ".weight"], s[n + ".bias"] = (c,), (c,)
+
+    def res_(n, ci, co):
+        norm_(n + ".norm1", ci); conv_(n + ".conv1", co, ci, 3); norm_(n + ".norm2", co); conv_(n + ".conv2", co, co, 3)
+        if ci != co:
+            conv_(n + ".conv_shortcut", co, ci, 1)
+    conv_("conv_in", ch[0], 3, 3)
+    cin = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(layers_per_block):
+            res_(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else co, co)
+        if i < len(ch) - 1:
+            conv_(f"down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+        cin = co
+    res_("mid_block.resnets.0", cin, cin); res_("mid_block.resnets.1", cin, cin)
+    a = "mid_block.attentions.0."
+    norm_(a + "group_norm", cin)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[a + n + ".weight"], s[a + n + ".bias"] = (cin, cin), (cin,)
+    norm_("conv_norm_out", cin)
+    conv_("conv_out", 2 * latent_channels, cin, 3)
+    return s
+
+
+def synthetic_decoder_state_dict(seed: int = 0, device="cpu", shapes=None, **kw):
+    """Seeded weights of that layout: convolutions / linears U(-1, 1) / sqrt(fan_in) (PyTorch's default scale), norm weights 1 + 0.2 N(0, 1).
+    `shapes=encoder_param_shapes()` draws an encoder."""
     g = torch.Generator(device=device).manual_seed(seed)
     sd = {}
-    for name, shape in decoder_param_shapes(**kw).items():
+    for name, shape in (decoder_param_shapes(**kw) if shapes is None else shapes).items():
         if name.endswith(".bias"):
             sd[name] = 0.1 * torch.randn(shape, generator=g, device=device)
         elif len(shape) == 1:
