@@ -359,9 +359,12 @@ int rgn_attention_plan_query(int Sq, int Skv, int H, size_t workspace_bytes);
  * Wt is the caller-built block-Toeplitz matrix [group * ldy, 3 * (group + 2) * Cin] (taps = 9; row p * ldy + c holds W[c, ky, kx] at
  * window pixel p + kx of kernel row ky, zeros elsewhere and in the padding channels) or [group * ldy, group * Cin] (taps = 1, block
  * diagonal); bias = [group * ldy].  The 256-wide tile is then full: MFMA work (group + 2) / 3 of the ideal instead of 256 / Cout.  Rows of Y
- * up to group - 1 past the image are written (zeros): the caller's guard rows. */
+ * up to group - 1 past the image are written (zeros): the caller's guard rows.
+ * gn_partial != NULL: the epilogue also leaves the GroupNorm(32) statistics of the STORED image in the caller's groupnorm workspace - per tile
+ * 32 x (sum, sum of squares), folded in a fixed order - and writes the tile count to *gn_blocks_host (a HOST int); passing that count as
+ * rgn_groupnorm_silu's `precomputed_blocks` skips its statistics pass (one read of the image less per ResNet half). */
 int rgn_conv_bf16(const void* X, int ldx, const void* Wt, const void* bias, const void* resid, void* Y, int ldy, int Hp, int Wp,
-                  int Cin, int Cout, int taps, int group, void* stream);
+                  int Cin, int Cout, int taps, int group, float* gn_partial, int* gn_blocks_host, void* stream);
 /* The encoder's downsampling convolution (VAE encode of the condition image, inside the host's `prepare_latents`, reference call site
  * FluxKontext/inplace.py:210-226): 3 x 3, stride 2, F.pad(x, (0, 1, 0, 1)) + padding 0.  X = padded image [Hp * Wp, Cin] (even H, W);
  * GEMM row m = yo * Wp + xo on the INPUT pitch (the A row is image row 2 m + Wp + 1: the same loop with a row stride of two pixels);
@@ -371,10 +374,12 @@ int rgn_conv_s2_bf16(const void* X, const void* Wt, const void* bias, void* Y, i
                      const int64_t* out_rows, void* stream);
 /* GroupNorm(32 groups) over the valid pixels + optional SiLU: Y = silu((X - mean_g) * rstd_g * gamma + beta), border rows of Y = 0.
  * C in {128, 256, 512}.  Statistics: per-block fp32 partial sums folded in a fixed order + one double-precision pass (no atomics:
- * bit-reproducible).  `workspace`: rgn_groupnorm_workspace_bytes() bytes, 16-byte aligned, one per stream. */
+ * bit-reproducible).  `workspace`: rgn_groupnorm_workspace_bytes() bytes, 16-byte aligned, one per stream.  precomputed_blocks > 0: X was
+ * written by rgn_conv_bf16 with gn_partial = this workspace, which left that many tiles' sums there: no statistics pass. */
 size_t rgn_groupnorm_workspace_bytes(void);
+size_t rgn_groupnorm_partial_bytes(void);          /* the leading part of the workspace a convolution's gn_partial may fill */
 int rgn_groupnorm_silu(const void* X, void* Y, int Hp, int Wp, int C, const void* gamma, const void* beta, float eps, int silu,
-                       void* workspace, void* stream);
+                       void* workspace, int precomputed_blocks, void* stream);
 /* Nearest-neighbour 2 x upsample of a padded image [Hp * Wp, C] into the padded image [(2 Hp - 2) * (2 Wp - 2), C] (border zero). */
 int rgn_upsample2x(const void* X, void* Y, int Hp, int Wp, int C, void* stream);
 /* Mid-block attention = three GEMMs (rgn_gemm_bf16) + this pass: S [Hp * Wp, ld] holds q . k for every (query, key) pixel of the

@@ -108,17 +108,19 @@ SIGNATURES = {
     "rgn_attention_workspace_bytes": [_c_int, _c_int],
     # f4: VAE decoder (implicit-GEMM convolutions + row kernels, csrc/vae.hip)
     "rgn_conv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                      _c_void_p],
+                      _c_void_p, C.POINTER(C.c_int), _c_void_p],
     "rgn_conv_s2_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "rgn_groupnorm_workspace_bytes": [],
-    "rgn_groupnorm_silu": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_void_p],
+    "rgn_groupnorm_partial_bytes": [],
+    "rgn_groupnorm_silu": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_int, _c_void_p],
     "rgn_upsample2x": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
     "rgn_softmax_rows": [_c_void_p, _c_int, _c_int, _c_int, _c_float, _c_void_p],
     "rgn_nchw_to_padded": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "rgn_padded_to_nchw": [_c_void_p, _c_int, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
 }
 _RESTYPE = {"rgn_last_error": C.c_char_p, "rgn_abi_struct_bytes": C.c_size_t, "rgn_attention_workspace_bytes": C.c_size_t,
-            "rgn_gemm_workspace_bytes": C.c_size_t, "rgn_groupnorm_workspace_bytes": C.c_size_t}
+            "rgn_gemm_workspace_bytes": C.c_size_t, "rgn_groupnorm_workspace_bytes": C.c_size_t,
+            "rgn_groupnorm_partial_bytes": C.c_size_t}
 
 _lib = None
 

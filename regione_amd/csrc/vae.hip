@@ -225,20 +225,27 @@ static inline int grid_for(size_t work_items, int per_block, int cap) {
     return (int)(g < 1 ? 1 : (g > (size_t)cap ? (size_t)cap : g));
 }
 
-size_t rgn_groupnorm_workspace_bytes(void) { return (size_t)(1024 * 64 + 64) * sizeof(float); }
+// workspace = [GN_MAX_BLOCKS][64] partial sums (the statistics kernel's blocks, or the tiles of the convolution that produced X) + 64 stats
+constexpr int GN_MAX_BLOCKS = 32768;
+size_t rgn_groupnorm_partial_bytes(void) { return (size_t)GN_MAX_BLOCKS * 64 * sizeof(float); }
+size_t rgn_groupnorm_workspace_bytes(void) { return rgn_groupnorm_partial_bytes() + 64 * sizeof(float); }
 
 int rgn_groupnorm_silu(const void* X, void* Y, int Hp, int Wp, int C, const void* gamma, const void* beta, float eps, int silu,
-                       void* workspace, void* stream) {
-    if (!X || !Y || !gamma || !beta || !workspace || Hp < 3 || Wp < 3) return fail(RGN_E_BADARG, "groupnorm: bad argument");
+                       void* workspace, int precomputed_blocks, void* stream) {
+    if (!X || !Y || !gamma || !beta || !workspace || Hp < 3 || Wp < 3 || precomputed_blocks < 0 || precomputed_blocks > GN_MAX_BLOCKS)
+        return fail(RGN_E_BADARG, "groupnorm: bad argument");
     if (C != 128 && C != 256 && C != 512) return fail(RGN_E_UNSUPPORTED, "groupnorm: 32 groups over 128 / 256 / 512 channels");
     if ((((uintptr_t)X | (uintptr_t)Y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)workspace) & 15) != 0)
         return fail(RGN_E_UNSUPPORTED, "groupnorm: pointers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int rows = Hp * Wp, rpb = 256 / (C / 8);
-    const int nb = grid_for((size_t)rows, rpb * 8, 1024);
     float* partial = (float*)workspace;
-    float* stats = partial + (size_t)1024 * 64;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nb), dim3(256), 0, st, (const uint16_t*)X, rows, C, partial);
+    float* stats = partial + (size_t)GN_MAX_BLOCKS * 64;
+    int nb = precomputed_blocks;
+    if (nb == 0) {           // else: the convolution that wrote X left its tiles' sums in `partial` (rgn_conv_bf16 gn_partial)
+        nb = grid_for((size_t)rows, rpb * 8, 1024);
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(nb), dim3(256), 0, st, (const uint16_t*)X, rows, C, partial);
+    }
     const double count = (double)(Hp - 2) * (Wp - 2) * (C / 32);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(1), dim3(1024), 0, st, partial, nb, count, eps, stats);
     const int nb2 = grid_for((size_t)rows, rpb * 4, 4096);

@@ -87,29 +87,46 @@ class ConvWeights:
             self.b = b.reshape(-1).to(torch.bfloat16).contiguous()
 
 
-def conv(x: PaddedImage, cw: ConvWeights, out: PaddedImage, resid: Optional[PaddedImage] = None):
-    """out = conv(x) + bias (+ resid), border rows zero (rgn_conv_bf16)."""
-    if cw.cin != x.C or out.C != cw.ldy or (resid is not None and (resid.C != out.C or resid.rows != out.rows)) or out.rows != x.rows:
-        raise _lib.RegionEHipError(f"conv: weights for {cw.cin} -> {cw.cout} (row stride {cw.ldy}) on images with {x.C} -> {out.C} channels")
-    rc = _lib.lib().rgn_conv_bf16(x.ptr(), x.C, _p(cw.w), _p(cw.b), None if resid is None else resid.ptr(), out.ptr(), out.C, x.Hp, x.Wp,
-                                  x.C, cw.cout, cw.taps, cw.group, _stream())
-    _lib.check(rc, "rgn_conv_bf16")
-    return out
-
-
 _gn_ws: Dict[Tuple[int, int], torch.Tensor] = {}
+_gn_owner: Dict[Tuple[int, int], Tuple[Optional["PaddedImage"], int]] = {}      # whose statistics the workspace's partial sums hold, tile count
+
+
+def _gn_key(device):
+    return (device.index if device.index is not None else torch.cuda.current_device(), _stream())
 
 
 def _gn_workspace(device) -> torch.Tensor:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), _stream())
+    key = _gn_key(device)
     if key not in _gn_ws:
         _gn_ws[key] = torch.empty(_lib.lib().rgn_groupnorm_workspace_bytes() // 4, dtype=torch.float32, device=device)
     return _gn_ws[key]
 
 
+def conv(x: PaddedImage, cw: ConvWeights, out: PaddedImage, resid: Optional[PaddedImage] = None, gn: bool = False):
+    """out = conv(x) + bias (+ resid), border rows zero (rgn_conv_bf16).  gn = True: the epilogue also leaves the GroupNorm statistics of `out`
+    in the stream's groupnorm workspace (the next `groupnorm_silu(out, ...)` then skips its statistics pass)."""
+    if cw.cin != x.C or out.C != cw.ldy or (resid is not None and (resid.C != out.C or resid.rows != out.rows)) or out.rows != x.rows:
+        raise _lib.RegionEHipError(f"conv: weights for {cw.cin} -> {cw.cout} (row stride {cw.ldy}) on images with {x.C} -> {out.C} channels")
+    import ctypes
+    dev = x.t.device
+    nblk = ctypes.c_int(0)
+    ws = _gn_workspace(dev) if gn else None
+    _gn_owner[_gn_key(dev)] = (None, 0)                  # whatever the workspace held is about to be overwritten (or is left stale: same answer)
+    rc = _lib.lib().rgn_conv_bf16(x.ptr(), x.C, _p(cw.w), _p(cw.b), None if resid is None else resid.ptr(), out.ptr(), out.C, x.Hp, x.Wp,
+                                  x.C, cw.cout, cw.taps, cw.group, _p(ws), ctypes.byref(nblk) if gn else None, _stream())
+    _lib.check(rc, "rgn_conv_bf16")
+    if gn:
+        _gn_owner[_gn_key(dev)] = (out, nblk.value)
+    return out
+
+
 def groupnorm_silu(x: PaddedImage, gamma: torch.Tensor, beta: torch.Tensor, out: PaddedImage, silu: bool = True, eps: float = 1e-6):
-    ws = _gn_workspace(x.t.device)
-    rc = _lib.lib().rgn_groupnorm_silu(x.ptr(), out.ptr(), x.Hp, x.Wp, x.C, _p(gamma), _p(beta), float(eps), int(silu), _p(ws), _stream())
+    dev = x.t.device
+    ws = _gn_workspace(dev)
+    owner, nblk = _gn_owner.get(_gn_key(dev), (None, 0))
+    pre = nblk if owner is x else 0                      # the convolution that wrote x left its tiles' sums in the workspace
+    _gn_owner[_gn_key(dev)] = (None, 0)                  # consumed
+    rc = _lib.lib().rgn_groupnorm_silu(x.ptr(), out.ptr(), x.Hp, x.Wp, x.C, _p(gamma), _p(beta), float(eps), int(silu), _p(ws), pre, _stream())
     _lib.check(rc, "rgn_groupnorm_silu")
     return out
 
@@ -235,6 +252,7 @@ class _KLBase:
         self.p: Dict[str, torch.Tensor] = {}
         self.c: Dict[str, ConvWeights] = {}
         self.pixel_groups = pixel_groups
+        self.fuse_gn = True              # GroupNorm statistics in the producing convolution's epilogue (False: the standalone statistics pass)
         self.pool = _Pool(self.device)
         self._attn_buf = {}
 
@@ -284,13 +302,13 @@ class _KLBase:
     def _run_resnet(self, x: PaddedImage, prefix: str, cout: int) -> PaddedImage:
         P, Cv, pool = self.p, self.c, self.pool
         n = groupnorm_silu(x, P[prefix + ".norm1.weight"], P[prefix + ".norm1.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
-        h = conv(n, Cv[prefix + ".conv1"], pool.get(x.H, x.W, cout))
+        h = conv(n, Cv[prefix + ".conv1"], pool.get(x.H, x.W, cout), gn=self.fuse_gn)
         pool.put(n)
         n2 = groupnorm_silu(h, P[prefix + ".norm2.weight"], P[prefix + ".norm2.bias"], pool.get(x.H, x.W, cout), eps=self.eps)
         skip = x
         if prefix + ".conv_shortcut" in Cv:
             skip = conv(x, Cv[prefix + ".conv_shortcut"], pool.get(x.H, x.W, cout))
-        conv(n2, Cv[prefix + ".conv2"], h, resid=skip)      # h is not an input of this launch
+        conv(n2, Cv[prefix + ".conv2"], h, resid=skip, gn=self.fuse_gn)      # h is not an input of this launch; every ResNet output feeds a GroupNorm
         pool.put(n2)
         if skip is not x:
             pool.put(skip)
@@ -316,7 +334,7 @@ class _KLBase:
         _lib.check(_lib.lib().rgn_softmax_rows(_p(S), ldp, x.Hp, x.Wp, 1.0 / math.sqrt(C), _stream()), "rgn_softmax_rows")
         o = q                                                                     # q is dead: O = P V + b_v
         ops.gemm(S, vt, P[a + "to_v.bias"], o.t)
-        out = conv(o, Cv[a + "to_out.0"], k, resid=x)       # k is dead
+        out = conv(o, Cv[a + "to_out.0"], k, resid=x, gn=self.fuse_gn)       # k is dead
         pool.put(n); pool.put(o); pool.put(x)
         return out
 
@@ -364,7 +382,7 @@ class HipVaeDecoder(_KLBase):
         zin = pool.get(h, w, 64)
         _lib.check(L.rgn_nchw_to_padded(_p(z), zin.ptr(), self.zc, h, w, 64, _stream()), "rgn_nchw_to_padded")
         top = self.ch[-1]
-        x = conv(zin, Cv["conv_in"], pool.get(h, w, top))
+        x = conv(zin, Cv["conv_in"], pool.get(h, w, top), gn=self.fuse_gn)
         pool.put(zin)
         x = self._run_resnet(x, "mid_block.resnets.0", top)
         x = self._run_attention(x)
@@ -375,7 +393,7 @@ class HipVaeDecoder(_KLBase):
             if up:
                 u = upsample2x(x, pool.get(2 * x.H, 2 * x.W, x.C))
                 pool.put(x)
-                x = conv(u, Cv[f"up_blocks.{i}.upsamplers.0.conv"], pool.get(u.H, u.W, u.C))
+                x = conv(u, Cv[f"up_blocks.{i}.upsamplers.0.conv"], pool.get(u.H, u.W, u.C), gn=self.fuse_gn)
                 pool.put(u)
         n = groupnorm_silu(x, P["conv_norm_out.weight"], P["conv_norm_out.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
         pool.put(x)
@@ -472,7 +490,7 @@ class HipVaeEncoder(_KLBase):
         P, Cv, pool, L = self.p, self.c, self.pool, _lib.lib()
         xin = pool.get(H, W, 64)
         _lib.check(L.rgn_nchw_to_padded(_p(x), xin.ptr(), 3, H, W, 64, _stream()), "rgn_nchw_to_padded")
-        h = conv(xin, Cv["conv_in"], pool.get(H, W, self.ch[0]))
+        h = conv(xin, Cv["conv_in"], pool.get(H, W, self.ch[0]), gn=self.fuse_gn)
         pool.put(xin)
         for i, (cin, co, down) in enumerate(self.levels):
             for j in range(self.nres):

@@ -43,12 +43,13 @@ def _border_is_zero(img):
 
 @pytest.mark.parametrize("H,W,cin,cout,group", [(16, 16, 128, 128, 1), (16, 16, 128, 128, 2), (24, 40, 256, 128, 2), (33, 17, 512, 256, 1),
                                                  (128, 128, 512, 512, 1), (72, 56, 64, 512, 1), (40, 72, 128, 3, 8), (25, 31, 128, 3, 8),
-                                                 (127, 129, 128, 128, 2)])
+                                                 (127, 129, 128, 128, 2), (258, 258, 64, 256, 1), (514, 258, 128, 128, 2)])
 @pytest.mark.parametrize("resid", [False, True])
 @pytest.mark.parametrize("geometry", [128, 256])
 def test_conv3x3_implicit_gemm_vs_torch(H, W, cin, cout, group, resid, geometry):
     """3 x 3 / stride 1 / zero padding 1 as an implicit GEMM over the zero-bordered image; both geometries (small images run on the
-    128 x 128 tiles, large on the hand-scheduled 256 x 256 loop); ragged sizes; the ResNet skip in the epilogue; zero border kept;
+    128 x 128 tiles, large on the hand-scheduled 256 x 256 loop; 258 x 258 / 514 x 258: whole rounds + a remainder as quarter tiles);
+    ragged sizes; the ResNet skip in the epilogue; zero border kept;
     pixel groups (block-Toeplitz weights: 2 pixels per GEMM row for 128 output channels, 8 for the RGB head with row stride 8)."""
     g = torch.Generator().manual_seed(H * 1000 + cin + cout)
     ldy = 8 if cout == 3 else cout
@@ -107,6 +108,37 @@ def test_groupnorm_silu_vs_torch(H, W, C, silu):
     out2 = V.PaddedImage(H, W, C, "cuda")
     V.groupnorm_silu(xi, gamma.to("cuda", torch.bfloat16), beta.to("cuda", torch.bfloat16), out2, silu=silu)
     assert torch.equal(out.t, out2.t)
+
+
+@pytest.mark.parametrize("H,W,cin,cout,group", [(24, 40, 128, 128, 2), (64, 64, 256, 256, 1), (33, 47, 512, 512, 1), (130, 126, 256, 128, 2),
+                                                 (128, 128, 64, 512, 1), (258, 258, 64, 256, 1), (514, 258, 128, 128, 2)])
+@pytest.mark.parametrize("geometry", [128, 256])
+def test_groupnorm_statistics_from_the_convolution_epilogue(H, W, cin, cout, group, geometry):
+    """rgn_conv_bf16(gn_partial): the statistics of the image the convolution stores (after bias, ResNet skip and border zeroing), so that the
+    GroupNorm that follows skips its own pass over it.  Same normalised image as the standalone pass up to the fp32 fold order of the sums."""
+    g = torch.Generator().manual_seed(H + W + cin)
+    x = torch.randn(1, cin, H, W, generator=g)
+    r = torch.randn(1, cout, H, W, generator=g) * 2.0 + 3.0 * torch.randn(1, cout, 1, 1, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g)
+    gamma, beta = (1.0 + 0.2 * torch.randn(cout, generator=g)).to("cuda", torch.bfloat16), (0.1 * torch.randn(cout, generator=g)).to("cuda", torch.bfloat16)
+    xi, ri = _padded(x), _padded(r)
+    cw = V.ConvWeights(w.permute(0, 2, 3, 1).cuda(), b.cuda(), group=group)
+    outs = []
+    for fused in (True, False):
+        y, n = V.PaddedImage(H, W, cout, "cuda"), V.PaddedImage(H, W, cout, "cuda")
+        with _lib.plan_override(gemm_geometry=geometry):
+            V.conv(xi, cw, y, resid=ri, gn=fused)
+        owner, nblk = V._gn_owner[V._gn_key(y.t.device)]
+        assert (owner is y and nblk > 0) if fused else owner is None
+        V.groupnorm_silu(y, gamma, beta, n)
+        assert V._gn_owner[V._gn_key(y.t.device)][0] is None           # consumed
+        torch.cuda.synchronize()
+        outs.append((_unpadded(y), _unpadded(n)))
+    assert torch.equal(outs[0][0], outs[1][0])                           # the convolution's output does not depend on the statistics option
+    assert _psnr(outs[0][1], outs[1][1].float()) >= 70.0
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(outs[0][0].double().cpu(), 32, gamma.double().cpu(), beta.double().cpu(), eps=1e-6)).float()
+    assert _psnr(outs[0][1], ref) >= 48.0
 
 
 def test_upsample2x_exact():
@@ -188,10 +220,12 @@ def _decoder_pair(seed, pixel_groups=True, **kw):
     return m, dec
 
 
-@pytest.mark.parametrize("h,w,groups", [(16, 16, True), (24, 40, True), (24, 40, False)])
-def test_decoder_small_latents_vs_fp32_module(h, w, groups):
-    """The whole decoder (every block type incl. the mid-block attention and the three upsamples) on small latents."""
+@pytest.mark.parametrize("h,w,groups,fuse", [(16, 16, True, True), (24, 40, True, True), (24, 40, False, True), (24, 40, True, False)])
+def test_decoder_small_latents_vs_fp32_module(h, w, groups, fuse):
+    """The whole decoder (every block type incl. the mid-block attention and the three upsamples) on small latents; with / without pixel groups
+    and with / without the GroupNorm statistics in the convolution epilogues."""
     m, dec = _decoder_pair(3, pixel_groups=groups)
+    dec.fuse_gn = fuse
     z = torch.randn(1, 16, h, w, generator=torch.Generator().manual_seed(h))
     with torch.no_grad():
         ref = m.decode(z.bfloat16().float(), return_dict=False)[0]
