@@ -9,7 +9,7 @@ tiles (the two S-register parities) - classifies every instruction and prices it
 
     v_mfma_f32_32x32x16_bf16   8 passes x 4 cycles = 32 cycles of the matrix pipe (32768 FLOP at 1024 FLOP / clk / SIMD = 2.5 PFLOP/s chip-wide), 4 issue cycles
     VALU fp32 / int / cvt_pk    4 cycles (one wave64 instruction on 16 lanes)
-    v_exp_f32 (transcendental) 16 cycles (quarter rate)
+    v_exp_f32 (transcendental) ~5/3 of a plain VALU instruction beside MFMAs = 6.7 cycles (MI355X_MICROARCH.md, two-wave pairing section)
     ds_read_b128                issue 4 cycles; LDS data path 64 lanes x 16 B / 128 B per clock = 8 cycles per CU-wide LDS port,
                                 shared by the CU's four SIMDs
     buffer_load ... lds         issue 4 cycles (+ ~60-185 cycles of address work on the issuing wave, measured in the microarch guide)
@@ -69,7 +69,7 @@ def main():
         cnt = collections.Counter(classify(i) for i in b)
         tiles = cnt["mfma"] / 32.0                       # 16 QK + 16 PV MFMAs per tile and wave
         per = {k: v / tiles for k, v in cnt.items()}
-        issue = {"mfma": 4, "valu": 4, "valu_acc": 4, "valu_trans": 16, "lds": 4, "vmem_dma": 4, "salu": 4, "waitcnt": 4, "barrier": 4, "other": 4}
+        issue = {"mfma": 4, "valu": 4, "valu_acc": 4, "valu_trans": 20.0 / 3.0, "lds": 4, "vmem_dma": 4, "salu": 4, "waitcnt": 4, "barrier": 4, "other": 4}
         print(f"## {macro}: {label}")
         print(f"loop body = {len(b)} instructions over {tiles:.0f} KV tiles (64 keys each) for one wave (32 query rows)")
         print(f"{'class':<12} {'per tile':>9} {'issue cyc':>10}")
@@ -81,28 +81,30 @@ def main():
                 if k in ("mfma", "valu", "valu_trans", "valu_acc", "lds", "vmem_dma"):
                     tot_vec += c
         mfma_pipe = per["mfma"] * 32
-        valu_busy = per.get("valu", 0) * 4 + per.get("valu_trans", 0) * 16 + per.get("valu_acc", 0) * 4
+        valu_busy = per.get("valu", 0) * 4 + per.get("valu_trans", 0) * 20.0 / 3.0 + per.get("valu_acc", 0) * 4
         lds_port = per.get("lds", 0) * 8 * 8 / 4.0        # 8 waves' reads through one CU port, seen from one SIMD's share of time: x 8 waves / 4 SIMDs
         print(f"per SIMD (TWO waves) and KV tile:")
         print(f"  matrix pipe busy      {2 * mfma_pipe:7.0f} cycles   (2 waves x {per['mfma']:.0f} MFMAs x 32)")
-        print(f"  VALU pipe busy        {2 * valu_busy:7.0f} cycles   (fp32 / cvt at 4, exp2 at 16 cycles per wave64 instruction)")
+        print(f"  VALU pipe busy        {2 * valu_busy:7.0f} cycles   (fp32 / cvt at 4, exp2 at 6.7 cycles per wave64 instruction)")
         print(f"  LDS port (CU-wide)    {per.get('lds', 0) * 8 * 8:7.0f} cycles   ({per.get('lds', 0):.0f} ds_read_b128 x 8 waves x 8 cycles of the 128 B/clk port)")
         tot_all = tot_vec + sum(per.get(k, 0) * 4 for k in ("salu", "waitcnt", "barrier", "other"))
-        print(f"  vector issue slots    {2 * tot_vec:7.0f} cycles   (every MFMA / VALU / LDS / VMEM instruction of both waves, 4 cycles each, exp2 16)")
+        print(f"  vector issue slots    {2 * tot_vec:7.0f} cycles   (every MFMA / VALU / LDS / VMEM instruction of both waves, 4 cycles each, exp2 6.7)")
         print(f"  ... + scalar / waits  {2 * tot_all:7.0f} cycles   (SALU, s_waitcnt, barrier: 4 each; upper bound - they can issue beside the other wave's vector op)")
         cyc = ns.tile_us * ns.clock_mhz
         print(f"  measured tile time    {cyc:7.0f} cycles   ({ns.tile_us} us at {ns.clock_mhz:.0f} MHz)")
         print(f"  => matrix pipe {2 * mfma_pipe / cyc:.2f} of the tile time, vector issue {2 * tot_vec / cyc:.2f}, VALU {2 * valu_busy / cyc:.2f}, LDS port {per.get('lds', 0) * 64 / cyc:.2f}")
         print()
-    print("Reading (static shift): per KV tile a SIMD owes 2048 cycles to the matrix pipe, 2048 to its share of the CU's LDS port, ~1800 to the VALU and")
-    print("2300-2800 issue cycles to its two waves; measured 3071.  MFMA busy = 2048 / 3071 = 0.67 (PMC: 0.686 on full rounds).  The largest single term -")
-    print("instruction issue - is within 10-25 % of the measured tile: even a perfect overlap of everything else would end at ~2800 cycles = 0.73 busy =")
-    print("0.52 of the 2.5 PFLOP/s peak at this kernel's clock share; the three co-limits (matrix, LDS port, issue) sit within 30 % of each other, so")
-    print("removing one class of instructions moves the tile by a fraction of its own share (static shift: -45 % VALU instructions, +3.7 % speed).")
-    print("What is left per tile and wave is 32 MFMA + 32 ds_read_b128 (each K / V^T fragment feeds")
-    print("exactly one MFMA: 32 query rows per wave; 64 rows per wave halves the reads and was measured slower, EXP 4.7) + the exp2 / convert / row-sum")
-    print("chain of 2048 scores per wave = 32 per lane, which no instruction of gfx950 does two at a time at full rate (v_pk_* fp32 is half rate on the")
-    print("MI355X: measured slower, `pkfma` / `pkadd` knobs of the generator).")
+    print("Reading (static shift): per KV tile a SIMD owes 2048 cycles to the matrix pipe, 2048 to its share of the CU's LDS read port, ~1200 to the VALU")
+    print("and ~1750-2200 issue cycles to its two waves; measured 3071 = 1.5 x the largest single-unit bound: NO single unit explains the tile time, so")
+    print("this budget does not prove a floor.  What it shows: (i) MFMA busy = 2048 / 3071 = 0.67 (PMC: 0.686 on full rounds) - the matrix pipe idles a")
+    print("third of the time although every other unit has slack on paper; (ii) the slack is lost in the PAIRING of the two waves of a SIMD, which the")
+    print("microarchitecture guide measures (VALU issue arbitrated by priority then age, a wave that loses VALU slots mid-stream also loses the MFMA")
+    print("cover those instructions provided; moving work between the two waves is zero- or negative-sum) and which rounds 1-5 met as: dephased roles")
+    print("-2 %, packed fp32 -3 %, v_dot2 row sums -1...-3.5 %, 4 waves x 64 rows slower, MFMA 16x16x32 in the QK product slower, static shift (45 %")
+    print("fewer VALU instructions) +3.7 % only; (iii) each K / V^T fragment read (32 ds_read_b128 per tile and wave) feeds exactly ONE MFMA - 8 waves")
+    print("read the same 32 KiB tile 8 times, which puts the LDS port level with the matrix pipe: the structural change left is a wave tile of 64")
+    print("query rows on ONE wave per SIMD with 512 registers (halves the reads per MFMA), whose first attempt (round 3, 4 waves x 64 rows, compiler-")
+    print("scheduled) lost to the 8-wave loop; a hand-scheduled version of it is the open experiment.")
 
 
 if __name__ == "__main__":
