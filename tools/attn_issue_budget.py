@@ -10,8 +10,8 @@ tiles (the two S-register parities) - classifies every instruction and prices it
     v_mfma_f32_32x32x16_bf16   8 passes x 4 cycles = 32 cycles of the matrix pipe (32768 FLOP at 1024 FLOP / clk / SIMD = 2.5 PFLOP/s chip-wide), 4 issue cycles
     VALU fp32 / int / cvt_pk    4 cycles (one wave64 instruction on 16 lanes)
     v_exp_f32 (transcendental) ~5/3 of a plain VALU instruction beside MFMAs = 6.7 cycles (MI355X_MICROARCH.md, two-wave pairing section)
-    ds_read_b128                issue 4 cycles; LDS data path 64 lanes x 16 B / 128 B per clock = 8 cycles per CU-wide LDS port,
-                                shared by the CU's four SIMDs
+    ds_read_b128                issue 4 cycles; LDS array 4 cycles per wave-instruction (256 B/clk/CU, MI355X_MICROARCH.md LDS table),
+                                one array per CU shared by its four SIMDs
     buffer_load ... lds         issue 4 cycles (+ ~60-185 cycles of address work on the issuing wave, measured in the microarch guide)
     SALU / waitcnt / barrier    4 cycles issue (scalar pipe, overlaps VALU issue of the OTHER wave)
 
@@ -86,23 +86,23 @@ def main():
         print(f"per SIMD (TWO waves) and KV tile:")
         print(f"  matrix pipe busy      {2 * mfma_pipe:7.0f} cycles   (2 waves x {per['mfma']:.0f} MFMAs x 32)")
         print(f"  VALU pipe busy        {2 * valu_busy:7.0f} cycles   (fp32 / cvt at 4, exp2 at 6.7 cycles per wave64 instruction)")
-        print(f"  LDS port (CU-wide)    {per.get('lds', 0) * 8 * 8:7.0f} cycles   ({per.get('lds', 0):.0f} ds_read_b128 x 8 waves x 8 cycles of the 128 B/clk port)")
+        print(f"  LDS array (CU-wide)   {per.get('lds', 0) * 8 * 4 + 256:7.0f} cycles   ({per.get('lds', 0):.0f} ds_read_b128 x 8 waves x 4 cycles + 32 KiB of LDS-DMA writes at 128 B/clk)")
         tot_all = tot_vec + sum(per.get(k, 0) * 4 for k in ("salu", "waitcnt", "barrier", "other"))
         print(f"  vector issue slots    {2 * tot_vec:7.0f} cycles   (every MFMA / VALU / LDS / VMEM instruction of both waves, 4 cycles each, exp2 6.7)")
         print(f"  ... + scalar / waits  {2 * tot_all:7.0f} cycles   (SALU, s_waitcnt, barrier: 4 each; upper bound - they can issue beside the other wave's vector op)")
         cyc = ns.tile_us * ns.clock_mhz
         print(f"  measured tile time    {cyc:7.0f} cycles   ({ns.tile_us} us at {ns.clock_mhz:.0f} MHz)")
-        print(f"  => matrix pipe {2 * mfma_pipe / cyc:.2f} of the tile time, vector issue {2 * tot_vec / cyc:.2f}, VALU {2 * valu_busy / cyc:.2f}, LDS port {per.get('lds', 0) * 64 / cyc:.2f}")
+        print(f"  => matrix pipe {2 * mfma_pipe / cyc:.2f} of the tile time, vector issue {2 * tot_vec / cyc:.2f}, VALU {2 * valu_busy / cyc:.2f}, LDS array {(per.get('lds', 0) * 32 + 256) / cyc:.2f}")
         print()
-    print("Reading (static shift): per KV tile a SIMD owes 2048 cycles to the matrix pipe, 2048 to its share of the CU's LDS read port, ~1200 to the VALU")
-    print("and ~1750-2200 issue cycles to its two waves; measured 3071 = 1.5 x the largest single-unit bound: NO single unit explains the tile time, so")
+    print("Reading (static shift): per KV tile a SIMD owes 2048 cycles to the matrix pipe, ~1300 to the CU's LDS array, ~1200 to the VALU and")
+    print("~1750-2200 issue cycles to its two waves; measured 3071 = 1.5 x the largest single-unit bound: NO single unit explains the tile time, so")
     print("this budget does not prove a floor.  What it shows: (i) MFMA busy = 2048 / 3071 = 0.67 (PMC: 0.686 on full rounds) - the matrix pipe idles a")
     print("third of the time although every other unit has slack on paper; (ii) the slack is lost in the PAIRING of the two waves of a SIMD, which the")
     print("microarchitecture guide measures (VALU issue arbitrated by priority then age, a wave that loses VALU slots mid-stream also loses the MFMA")
     print("cover those instructions provided; moving work between the two waves is zero- or negative-sum) and which rounds 1-5 met as: dephased roles")
     print("-2 %, packed fp32 -3 %, v_dot2 row sums -1...-3.5 %, 4 waves x 64 rows slower, MFMA 16x16x32 in the QK product slower, static shift (45 %")
     print("fewer VALU instructions) +3.7 % only; (iii) each K / V^T fragment read (32 ds_read_b128 per tile and wave) feeds exactly ONE MFMA - 8 waves")
-    print("read the same 32 KiB tile 8 times, which puts the LDS port level with the matrix pipe: the structural change left is a wave tile of 64")
+    print("read the same 32 KiB tile 8 times (64 reads in flight per SIMD and tile next to 64 MFMAs): the structural change left is a wave tile of 64")
     print("query rows on ONE wave per SIMD with 512 registers (halves the reads per MFMA), whose first attempt (round 3, 4 waves x 64 rows, compiler-")
     print("scheduled) lost to the 8-wave loop; a hand-scheduled version of it is the open experiment.")
 
