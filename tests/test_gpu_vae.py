@@ -288,3 +288,21 @@ def test_decoder_rejects_what_it_does_not_implement():
     dec = V.HipVaeDecoder(m.state_dict(), "cuda")
     with pytest.raises(_lib.RegionEHipError):
         dec.decode(torch.zeros(1, 16, 8, 8))                 # CPU tensor: no fallback
+
+
+def test_every_gpu_kernel_of_a_decode_and_an_encode_is_a_libregione_hip_kernel():
+    """SURVEY.md section 7 "no Python fallback on the GPU path", for the f4 kernels: a warm decode / encode (buffers of this size pooled, weights
+    re-laid at adoption) dispatches `rgn::` kernels only - no at::native elementwise / fill / copy kernel."""
+    from tests.test_gpu_no_eager_kernels import _foreign, _gpu_activity_names
+    m = host_vae.seeded(2)
+    dec, enc = V.HipVaeDecoder(m.state_dict(), "cuda"), V.HipVaeEncoder(m.state_dict(), "cuda")
+    z = torch.randn(1, 16, 24, 32).to("cuda", torch.bfloat16)
+    x = torch.randn(1, 3, 192, 256).clamp(-1, 1).to("cuda", torch.bfloat16)
+    dec.decode(z), enc.encode(x)                              # warm
+    torch.cuda.synchronize()
+    img, names = _gpu_activity_names(lambda: dec.decode(z))
+    assert len(names) > 90 and any("gemm_bf16_kernel" in n for n in names) and any("gn_apply_kernel" in n for n in names), names[:5]
+    assert _foreign(names) == [], _foreign(names)
+    mom, names = _gpu_activity_names(lambda: enc.encode(x))
+    assert len(names) > 60 and _foreign(names) == [], _foreign(names)
+    assert img.shape == (1, 3, 192, 256) and mom.shape == (1, 32, 24, 32)
