@@ -16,7 +16,7 @@ host runs) and times them on the MI355X next to the HIP denoise loop of the same
 
 Random weights change no timing (dense convolutions / GEMMs); the figures are the host's share of an end-to-end edit.
 
-    python tools/f4_host_side.py > profiles/r05_f4_host_side.json
+    python tools/f4_host_side.py > profiles/r06_f4_host_side.json
 """
 import json
 import os
@@ -183,6 +183,13 @@ def main():
     res["vae_decode_s"] = timed(lambda: dec(z))
     res["vae_params_m"] = round((nparams(enc) + nparams(dec)) / 1e6, 1)
     del enc, dec
+    # round 6: the same two stages on libregione_hip.so (regione_amd/vae.py; synthetic weights of the diffusers layout)
+    from regione_amd import vae as V
+    hdec = V.HipVaeDecoder(V.synthetic_decoder_state_dict(3, device=dev), dev)
+    henc = V.HipVaeEncoder(V.synthetic_decoder_state_dict(4, device=dev, shapes=V.encoder_param_shapes()), dev)
+    res["hip_vae_encode_s"] = timed(lambda: henc.encode(img.clamp(-1, 1)))
+    res["hip_vae_decode_s"] = timed(lambda: hdec.decode(z))
+    del hdec, henc
     t5 = T5Encoder().to(dev, bf)
     ids = torch.randint(0, 32000, (1, 512), device=dev)
     res["t5_xxl_512_tokens_s"] = timed(lambda: t5(ids))
@@ -216,6 +223,10 @@ def main():
     tot = res["encode_s"] + res["loop_s"] + res["decode_s"]
     res["end_to_end_s"] = tot
     res["host_share_of_end_to_end"] = (res["encode_s"] + res["decode_s"]) / tot
+    hip_tot = res["hip_vae_encode_s"] + res["t5_xxl_512_tokens_s"] + res["clip_l_77_tokens_s"] + res["loop_s"] + res["hip_vae_decode_s"]
+    res["end_to_end_hip_vae_s"] = hip_tot
+    res["host_share_of_end_to_end_hip_vae"] = (res["t5_xxl_512_tokens_s"] + res["clip_l_77_tokens_s"]) / hip_tot
+    res["end_to_end_speedup_vs_full_token_loop_hip_vae"] = (hip_tot - res["loop_s"] + res["loop_full_token_s"]) / hip_tot
     res["end_to_end_speedup_vs_full_token_loop"] = (res["encode_s"] + res["loop_full_token_s"] + res["decode_s"]) / tot
     print(json.dumps(res, indent=1))
 

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-5 measurement pass on one MI355X box (everything the bench line's roofline / mfma_busy / traffic fields and DESIGN section 5
+# Measurement pass (round = $RND, default r06) on one MI355X box (everything the bench line's roofline / mfma_busy / traffic fields and DESIGN section 5
 # quote): sustained clock / power probes, rocprofv3 --pmc passes (own runs, --kernel-trace only), a kernel-trace summary and the default
 # bench line, all from the SAME kernel sources (csrc_sha16 stamp).  Writes gpurun_out/r05/; the summaries are copied to profiles/.
 set -x
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r05
+RND=${RND:-r06}
+O=$R/gpurun_out/$RND
 mkdir -p $O/pmc
 cd $R
 for k in gemm attn vendor vendor_attn gemv edit; do python tools/clock_probe.py $k --json 2>/dev/null | tail -1 > $O/clock_$k.json; done
@@ -25,7 +26,7 @@ LAT=$(find /tmp/plat -name "lat_results.db" | head -1)
 python tools/pmc_traffic.py $(find /tmp/prd -name "rd_results.db" | head -1) $(find /tmp/pwr -name "wr_results.db" | head -1) --edits 2 ${LAT:+--lat-db $LAT} > $O/pmc_traffic.json
 { echo "# rocprofv3 --kernel-trace of: python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vanilla --no-5pct (5 RegionE edits: 1 warm-up, 1 characterising, 3 timed); bench line of the same process: bench_rocprof_run.json"; python tools/probes/kernel_avg.py $(find /tmp/kt -name "kt_results.db" | head -1); } > $O/kernel_stats.txt
 # the bench line quotes traffic / mfma_busy only from profiles/ files of the SAME kernel sources: put this pass's summaries there first
-cp $O/pmc_mfma.json $R/profiles/r05_pmc_mfma.json; cp $O/pmc_traffic.json $R/profiles/r05_pmc_traffic.json
+cp $O/pmc_mfma.json $R/profiles/${RND}_pmc_mfma.json; cp $O/pmc_traffic.json $R/profiles/${RND}_pmc_traffic.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --steps 20 --warmup 5 > $O/bench_steps20_warmup5.json 2>/dev/null
 tail -c 600 $O/bench_default.json; head -14 $O/kernel_stats.txt | cut -c1-160
