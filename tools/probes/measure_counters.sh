@@ -23,7 +23,7 @@ rocprofv3 --kernel-trace -d /tmp/kt -o kt -- python $R/bench.py --steps 3 --warm
 cd $R
 python tools/pmc_summary.py $(find /tmp/pm -name "m_results.db" | head -1) > $O/pmc_mfma.json
 LAT=$(find /tmp/plat -name "lat_results.db" | head -1)
-python tools/pmc_traffic.py $(find /tmp/prd -name "rd_results.db" | head -1) $(find /tmp/pwr -name "wr_results.db" | head -1) --edits 2 ${LAT:+--lat-db $LAT} > $O/pmc_traffic.json
+python tools/pmc_traffic.py $(find /tmp/prd -name "rd_results.db" | head -1) $(find /tmp/pwr -name "wr_results.db" | head -1) --edits 3 ${LAT:+--lat-db $LAT} > $O/pmc_traffic.json
 { echo "# rocprofv3 --kernel-trace of: python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vanilla --no-5pct (5 RegionE edits: 1 warm-up, 1 characterising, 3 timed); bench line of the same process: bench_rocprof_run.json"; python tools/probes/kernel_avg.py $(find /tmp/kt -name "kt_results.db" | head -1); } > $O/kernel_stats.txt
 # the bench line quotes traffic / mfma_busy only from profiles/ files of the SAME kernel sources: put this pass's summaries there first
 cp $O/pmc_mfma.json $R/profiles/${RND}_pmc_mfma.json; cp $O/pmc_traffic.json $R/profiles/${RND}_pmc_traffic.json
