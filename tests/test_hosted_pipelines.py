@@ -236,3 +236,45 @@ def test_flux_hosted_decode_runs_on_the_hip_vae():
     # a VAE without the AutoencoderKL layout (the stand-in of the other tests) is not touched
     pipe2 = HS.FluxKontextPipeline(HS.stub_trunk("flux"))
     assert A.hip_vae_for(pipe2, torch.device("cuda", 0)) is None and pipe2._regione_hip_vae is None
+
+
+def test_step1x_hosted_encode_and_decode_run_on_the_hip_vae():
+    """The Step1X-Edit pipelines make the same two VAE calls (Step1XEdit/inplace.py `prepare_latents` / `self.vae.decode`): a hosted Step1X
+    pipeline whose `vae` is an AutoencoderKL gets both on the HIP kernels too; the host module's own methods are never entered."""
+    import host_vae
+    from regione_amd import vae as V
+
+    class KL(host_vae.AutoencoderKLStandIn):
+        dtype = torch.float32
+        config = HS.Vae.config
+        n = 0
+
+        def decode(self, z, return_dict=True):
+            KL.n += 1
+            return super().decode(z, return_dict=return_dict)
+
+        def encode(self, x, return_dict=True):
+            KL.n += 1
+            return super().encode(x, return_dict=return_dict)
+
+    class Step1XEditPipeline(HS.Step1XEditPipeline):             # RegionEHelper dispatches on the class NAME
+        def _latents(self, image, dtype, generator, latents):
+            z = self.vae.encode(image).latent_dist.mode()
+            image_latents = self._pack_latents(z.float().cpu()).to(dtype)
+            if latents is None:
+                latents = torch.randn(image_latents.shape, generator=generator).to(dtype)
+            return latents, image_latents
+
+    torch.manual_seed(12)
+    trunk = HS.stub_trunk("step1x")
+    pipe = Step1XEditPipeline(trunk)
+    object.__setattr__(trunk, "connector", HS.ToyConnector().to(torch.bfloat16))
+    pipe.vae = KL().eval()
+    helper = RegionEHelper(pipe)
+    helper.set_params(threshold=0.5)
+    helper.enable()
+    out = pipe(image=_picture(), prompt="turn the sky green", generator=_gen(), output_type="pt", latents=None)
+    assert tuple(out.images.shape) == (1, 3, 256, 256) and torch.isfinite(out.images.float()).all()
+    assert isinstance(pipe._regione_hip_vae, V.HipVaeDecoder) and isinstance(pipe._regione_hip_vae_encoder, V.HipVaeEncoder) and KL.n == 0
+    assert "encode" not in pipe.vae.__dict__
+    helper.disable()
