@@ -36,7 +36,7 @@ extern "C" {
  * with, rgn_abi_struct_bytes() = sizeof(rgn_qkv_epilogue) * 1000 + sizeof(rgn_gemm_problem) as the library sees them: a binding
  * compiled against another header (a stale libregione_torch.so next to a rebuilt libregione_hip.so) compares both at load time
  * and refuses to run instead of misreading structs passed by pointer. */
-#define RGN_ABI_VERSION 106
+#define RGN_ABI_VERSION 107
 int rgn_version(void);
 size_t rgn_abi_struct_bytes(void);
 const char* rgn_last_error(void);
@@ -372,6 +372,14 @@ int rgn_conv_bf16(const void* X, int ldx, const void* Wt, const void* bias, cons
  * pixel (yo, xo) for xo < W / 2, a scratch row for the unused columns of the wide grid.  Wt = [Cout, 3, 3, Cin]; no border test. */
 int rgn_conv_s2_bf16(const void* X, const void* Wt, const void* bias, void* Y, int ldy, int Hp, int Wp, int Cin, int Cout,
                      const int64_t* out_rows, void* stream);
+/* The decoder's `upsamplers.0` (nearest 2 x upsample, then a 3 x 3 convolution) WITHOUT the upsampled image: every output phase (a, b) of
+ * pixel (2y + a, 2x + b) is a 2 x 2 convolution of the LOW-resolution image X [Hp * Wp, Cin] with tap-summed weights (16 / 36 of the FLOPs).
+ * Wt4 = [4 phases (a * 2 + b)][Cout, 2, 2, Cin] (caller: kernel row 0 / 1 of phase a = 0 holds w[0] / w[1] + w[2], of a = 1 w[0] + w[1] / w[2];
+ * columns alike with b); out_rows4 = [4][Hp * Wp] int64 (device): the row of the high-resolution padded image Y each low-resolution padded pixel's
+ * phase is stored to (border pixels: a scratch row; their values are zeroed); Y's own border rows are not written (the caller keeps them
+ * zero).  One launch of four problems.  gn_partial / gn_blocks_host as rgn_conv_bf16 (the statistics of all of Y). */
+int rgn_conv_up2_bf16(const void* X, const void* Wt4, const void* bias, void* Y, int ldy, int Hp, int Wp, int Cin, int Cout,
+                      const int64_t* out_rows4, float* gn_partial, int* gn_blocks_host, void* stream);
 /* GroupNorm(32 groups) over the valid pixels + optional SiLU: Y = silu((X - mean_g) * rstd_g * gamma + beta), border rows of Y = 0.
  * C in {128, 256, 512}.  Statistics: per-block fp32 partial sums folded in a fixed order + one double-precision pass (no atomics:
  * bit-reproducible).  `workspace`: rgn_groupnorm_workspace_bytes() bytes, 16-byte aligned, one per stream.  precomputed_blocks > 0: X was

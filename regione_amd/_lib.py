@@ -110,6 +110,8 @@ SIGNATURES = {
     "rgn_conv_bf16": [_c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                       _c_void_p, C.POINTER(C.c_int), _c_void_p],
     "rgn_conv_s2_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
+    "rgn_conv_up2_bf16": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p,
+                          C.POINTER(C.c_int), _c_void_p],
     "rgn_groupnorm_workspace_bytes": [],
     "rgn_groupnorm_partial_bytes": [],
     "rgn_groupnorm_silu": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_float, _c_int, _c_void_p, _c_int, _c_void_p],

@@ -232,6 +232,63 @@ def conv_s2(x: PaddedImage, cw: "ConvWeights", out: PaddedImage, rows_table: tor
     return out
 
 
+class UpConvWeights:
+    """`upsamplers.0.conv` for rgn_conv_up2_bf16: the four phase matrices [4][Cout, 2, 2, Cin] with the taps a low-resolution pixel is seen
+    through summed (in fp32, then rounded to bf16 once).  `w4`: [Cout, 3, 3, Cin] fp32."""
+
+    def __init__(self, w4: torch.Tensor, bias: torch.Tensor):
+        co, kh, kw, ci = w4.shape
+        assert kh == 3 and kw == 3
+        self.cout, self.cin = co, ci
+        fold = ([[0], [1, 2]], [[0, 1], [2]])                    # phase 0: window rows (y - 1, y) <- taps (0), (1, 2); phase 1: (y, y + 1) <- (0, 1), (2)
+        mats = []
+        for a in range(2):
+            for b in range(2):
+                t = torch.zeros((co, 2, 2, ci), dtype=torch.float32, device=w4.device)
+                for r in range(2):
+                    for c in range(2):
+                        for ky in fold[a][r]:
+                            for kx in fold[b][c]:
+                                t[:, r, c, :] += w4[:, ky, kx, :]
+                mats.append(t.reshape(co, -1))
+        self.w = torch.stack(mats).to(torch.bfloat16).contiguous()
+        self.b = bias.to(w4.device, torch.bfloat16).contiguous()
+
+
+def upsample_rows(H: int, W: int, device) -> torch.Tensor:
+    """rgn_conv_up2_bf16's row tables [4][(H + 2) * (W + 2)] for an H x W low-resolution image: low-resolution padded pixel (py, px), phase
+    (a, b) -> padded row of pixel (2 (py - 1) + a, 2 (px - 1) + b) of the (2H + 2) x (2W + 2) image; border pixels -> the first guard row
+    behind that image.  Built once per size (setup)."""
+    Hp, Wp, Wq = H + 2, W + 2, 2 * W + 2
+    m = torch.arange(Hp * Wp, dtype=torch.int64, device=device)
+    py, px = m // Wp, m % Wp
+    ok = (py >= 1) & (py <= H) & (px >= 1) & (px <= W)
+    scratch = (2 * H + 2) * Wq
+    out = []
+    for a in range(2):
+        for b in range(2):
+            row = (2 * (py - 1) + a + 1) * Wq + 2 * (px - 1) + b + 1
+            out.append(torch.where(ok, row, torch.full_like(row, scratch)))
+    return torch.stack(out).contiguous()
+
+
+def conv_up2(x: PaddedImage, uw: UpConvWeights, out: PaddedImage, rows_table: torch.Tensor, gn: bool = False):
+    """out = conv3x3(upsample2x(x)) + bias without the upsampled image (rgn_conv_up2_bf16); `rows_table` = upsample_rows(x.H, x.W)."""
+    if uw.cin != x.C or out.C != uw.cout or out.H != 2 * x.H or out.W != 2 * x.W:
+        raise _lib.RegionEHipError(f"conv_up2: weights for {uw.cin} -> {uw.cout} on {x.H} x {x.W} x {x.C} -> {out.H} x {out.W} x {out.C}")
+    import ctypes
+    dev = x.t.device
+    nblk = ctypes.c_int(0)
+    ws = _gn_workspace(dev) if gn else None
+    _gn_owner[_gn_key(dev)] = (None, 0)
+    rc = _lib.lib().rgn_conv_up2_bf16(x.ptr(), _p(uw.w), _p(uw.b), out.ptr(), out.C, x.Hp, x.Wp, x.C, uw.cout, _p(rows_table), _p(ws),
+                                      ctypes.byref(nblk) if gn else None, _stream())
+    _lib.check(rc, "rgn_conv_up2_bf16")
+    if gn:
+        _gn_owner[_gn_key(dev)] = (out, nblk.value)
+    return out
+
+
 def downsample_rows(H: int, W: int, device) -> torch.Tensor:
     """rgn_conv_s2_bf16's row table for an H x W input (padded pitch W + 2): GEMM row m = yo * (W + 2) + xo -> padded row of output pixel
     (yo, xo) in the (H / 2 + 2) x (W / 2 + 2) image, or - for the unused columns xo >= W / 2 of the wide grid - the first guard row behind
@@ -347,6 +404,9 @@ class HipVaeDecoder(_KLBase):
         self.ch = tuple(block_out_channels)
         self.zc, self.nres, self.eps = latent_channels, layers_per_block + 1, norm_eps
         self._init_params(state_dict, device, "decoder.", pixel_groups)
+        self.u: Dict[str, UpConvWeights] = {}
+        self.fuse_upsample = True        # nearest 2 x upsample folded into its convolution (rgn_conv_up2_bf16); False: upsample pass + 3 x 3
+        self._up_rows = {}
         top = self.ch[-1]
         for c in self.ch:
             if c not in (128, 256, 512):
@@ -362,7 +422,10 @@ class HipVaeDecoder(_KLBase):
                 self._resnet(f"up_blocks.{i}.resnets.{j}")
             up = i < len(self.ch) - 1
             if up:
-                self._conv(f"up_blocks.{i}.upsamplers.0.conv")
+                n = f"up_blocks.{i}.upsamplers.0.conv"
+                w = self._sd[n + ".weight"].to(self.device, torch.float32).permute(0, 2, 3, 1)
+                self.u[n] = UpConvWeights(w, self._sd[n + ".bias"])          # the fused upsample + convolution (four 2 x 2 phases)
+                self._conv(n)                                               # and the plain form (fuse_upsample = False)
             self.levels.append((cin, co, up))
             cin = co
         self._vec("conv_norm_out.weight"); self._vec("conv_norm_out.bias")
@@ -391,10 +454,19 @@ class HipVaeDecoder(_KLBase):
             for j in range(self.nres):
                 x = self._run_resnet(x, f"up_blocks.{i}.resnets.{j}", co)
             if up:
-                u = upsample2x(x, pool.get(2 * x.H, 2 * x.W, x.C))
-                pool.put(x)
-                x = conv(u, Cv[f"up_blocks.{i}.upsamplers.0.conv"], pool.get(u.H, u.W, u.C), gn=self.fuse_gn)
-                pool.put(u)
+                name = f"up_blocks.{i}.upsamplers.0.conv"
+                if self.fuse_upsample:
+                    key = (x.H, x.W)
+                    if key not in self._up_rows:
+                        self._up_rows[key] = upsample_rows(x.H, x.W, self.device)
+                    y = conv_up2(x, self.u[name], pool.get(2 * x.H, 2 * x.W, x.C), self._up_rows[key], gn=self.fuse_gn)
+                    pool.put(x)
+                    x = y
+                else:
+                    u = upsample2x(x, pool.get(2 * x.H, 2 * x.W, x.C))
+                    pool.put(x)
+                    x = conv(u, Cv[name], pool.get(u.H, u.W, u.C), gn=self.fuse_gn)
+                    pool.put(u)
         n = groupnorm_silu(x, P["conv_norm_out.weight"], P["conv_norm_out.bias"], pool.get(x.H, x.W, x.C), eps=self.eps)
         pool.put(x)
         y = conv(n, Cv["conv_out"], pool.get(n.H, n.W, 8))

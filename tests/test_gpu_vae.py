@@ -141,6 +141,32 @@ def test_groupnorm_statistics_from_the_convolution_epilogue(H, W, cin, cout, gro
     assert _psnr(outs[0][1], ref) >= 48.0
 
 
+@pytest.mark.parametrize("H,W,C", [(16, 16, 256), (19, 23, 512), (128, 128, 512), (256, 256, 256), (40, 24, 128)])
+@pytest.mark.parametrize("geometry", [128, 256])
+def test_upsample_folded_into_its_convolution_vs_torch(H, W, C, geometry):
+    """rgn_conv_up2_bf16: conv3x3(nearest 2 x upsample(x)) as four 2 x 2 phase convolutions of the low-resolution image (one launch of four
+    problems, tap-summed weights, row tables) against interpolate + conv2d; zero border; GroupNorm statistics of the whole output."""
+    g = torch.Generator().manual_seed(H * 7 + C)
+    x = torch.randn(1, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    b = torch.randn(C, generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.bfloat16().double(), scale_factor=2.0, mode="nearest"), w.bfloat16().double(),
+                                     b.bfloat16().double(), padding=1).float()
+    xi, out = _padded(x), V.PaddedImage(2 * H, 2 * W, C, "cuda")
+    uw = V.UpConvWeights(w.permute(0, 2, 3, 1).cuda(), b.cuda())
+    with _lib.plan_override(gemm_geometry=geometry):
+        V.conv_up2(xi, uw, out, V.upsample_rows(H, W, "cuda"), gn=True)
+    torch.cuda.synchronize()
+    assert _border_is_zero(out)
+    assert _psnr(_unpadded(out), ref) >= 44.0, _psnr(_unpadded(out), ref)        # tap sums are rounded to bf16 once: a hair below the plain form
+    gamma, beta = torch.ones(C, device="cuda", dtype=torch.bfloat16), torch.zeros(C, device="cuda", dtype=torch.bfloat16)
+    n1, n2 = V.PaddedImage(2 * H, 2 * W, C, "cuda"), V.PaddedImage(2 * H, 2 * W, C, "cuda")
+    V.groupnorm_silu(out, gamma, beta, n1)                                       # statistics from the four problems' tiles
+    V.groupnorm_silu(out, gamma, beta, n2)                                       # consumed: the standalone pass
+    torch.cuda.synchronize()
+    assert _psnr(_unpadded(n1), _unpadded(n2).float()) >= 70.0
+
+
 def test_upsample2x_exact():
     x = torch.randn(1, 256, 19, 23)
     xi = _padded(x)
@@ -220,12 +246,14 @@ def _decoder_pair(seed, pixel_groups=True, **kw):
     return m, dec
 
 
-@pytest.mark.parametrize("h,w,groups,fuse", [(16, 16, True, True), (24, 40, True, True), (24, 40, False, True), (24, 40, True, False)])
+@pytest.mark.parametrize("h,w,groups,fuse", [(16, 16, True, True), (24, 40, True, True), (24, 40, False, True), (24, 40, True, False),
+                                             (24, 40, True, "plain_upsample")])
 def test_decoder_small_latents_vs_fp32_module(h, w, groups, fuse):
     """The whole decoder (every block type incl. the mid-block attention and the three upsamples) on small latents; with / without pixel groups
     and with / without the GroupNorm statistics in the convolution epilogues."""
     m, dec = _decoder_pair(3, pixel_groups=groups)
-    dec.fuse_gn = fuse
+    dec.fuse_gn = bool(fuse)
+    dec.fuse_upsample = fuse != "plain_upsample"
     z = torch.randn(1, 16, h, w, generator=torch.Generator().manual_seed(h))
     with torch.no_grad():
         ref = m.decode(z.bfloat16().float(), return_dict=False)[0]

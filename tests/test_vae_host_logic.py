@@ -121,3 +121,41 @@ def test_decoder_flops_formula():
     """10.47 TFLOP for the 1024 x 1024 decode (the figure bench.py's end_to_end.vae_decode_tflops divides by the time)."""
     f = V.HipVaeDecoder.flops.__get__(type("D", (), dict(ch=(128, 256, 512, 512), zc=16, nres=3, levels=[(512, 512, True), (512, 512, True), (512, 256, True), (256, 128, False)]))())(128, 128)
     assert abs(f / 1e12 - 10.47) < 0.05, f
+
+
+def test_upsample_folded_into_its_convolution_four_phases_equal_interpolate_then_conv2d():
+    """rgn_conv_up2_bf16's host side: tap-summed 2 x 2 phase weights + the row tables, emulated as four GEMMs over the LOW-resolution image."""
+    g = torch.Generator().manual_seed(3)
+    H, W, ci, co = 5, 7, 3, 4
+    x = torch.randn(1, ci, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(co, ci, 3, 3, generator=g, dtype=torch.float64)
+    b = torch.randn(co, generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)[0].permute(1, 2, 0)
+    uw = V.UpConvWeights(w.permute(0, 2, 3, 1).float(), b.float())
+    assert tuple(uw.w.shape) == (4, co, 4 * ci)
+    fold = ([[0], [1, 2]], [[0, 1], [2]])
+    Wp, Hp = W + 2, H + 2
+    flat, base = _padded_rows(x, guard=Wp + 8)
+    table = V.upsample_rows(H, W, "cpu")
+    Wq = 2 * W + 2
+    dst = torch.zeros((2 * H + 2) * Wq + 1, co, dtype=torch.float64)
+    for ph in range(4):
+        a, bb = ph >> 1, ph & 1
+        Wm = torch.zeros(co, 2, 2, ci, dtype=torch.float64)
+        for r in range(2):
+            for c in range(2):
+                for ky in fold[a][r]:
+                    for kx in fold[bb][c]:
+                        Wm[:, r, c, :] += w.permute(0, 2, 3, 1)[:, ky, kx, :]
+        assert torch.allclose(uw.w[ph].double(), Wm.reshape(co, -1), atol=3e-2, rtol=3e-2)
+        rows = []
+        for m in range(Hp * Wp):
+            p0 = base + m + (a - 1) * Wp + (bb - 1)
+            rows.append(torch.cat([flat[p0 + kr * Wp: p0 + kr * Wp + 2].reshape(-1) for kr in range(2)]))
+        out = torch.stack(rows) @ Wm.reshape(co, -1).T + b
+        dst[table[ph]] = out
+    got = dst[:-1].reshape(2 * H + 2, Wq, co)
+    assert torch.allclose(got[1:-1, 1:-1], ref, atol=1e-9)
+    assert torch.count_nonzero(got[0]) == 0 and torch.count_nonzero(got[:, 0]) == 0 and torch.count_nonzero(got[-1]) == 0 and torch.count_nonzero(got[:, -1]) == 0
+    valid = table[table < (2 * H + 2) * Wq]
+    assert valid.numel() == 4 * H * W and len(set(valid.tolist())) == 4 * H * W          # every high-resolution pixel exactly once
