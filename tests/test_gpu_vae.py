@@ -20,6 +20,18 @@ def _psnr(a, b):
     return 10 * math.log10(peak * peak / max(mse, 1e-30))
 
 
+def _fp32_on_cpu(fn):
+    """The fp32 PyTorch reference on the host cores (test infrastructure): at 1024 x 1024 the CPU is several times faster than the first call
+    of the GPU library's fp32 convolutions; 64 threads (more is slower on the 128-core box)."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(n, 64))
+    try:
+        with torch.no_grad():
+            return fn()
+    finally:
+        torch.set_num_threads(n)
+
+
 def _padded(x_nchw, cpad=None):
     """[1, C, H, W] fp32 -> PaddedImage (bf16)"""
     _, C, H, W = x_nchw.shape
@@ -204,9 +216,8 @@ def test_encoder_vs_fp32_module(H, W):
     m = host_vae.seeded(7)
     enc = V.HipVaeEncoder(m.state_dict(), "cuda")
     x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(H)).clamp(-1, 1)
+    ref = _fp32_on_cpu(lambda: m.encoder(x.bfloat16().float()))
     mg = m.cuda()
-    with torch.no_grad():
-        ref = mg.encoder(x.bfloat16().float().cuda()).cpu()
     got = enc.encode(x.cuda())
     torch.cuda.synchronize()
     assert got.shape == (1, 32, H // 8, W // 8) and torch.isfinite(got.float()).all()
@@ -268,14 +279,13 @@ def test_decoder_small_latents_vs_fp32_module(h, w, groups, fuse):
 
 def test_decoder_1024_vs_fp32_module_and_timing():
     """The headline size: 128 x 128 x 16 latent -> 1024 x 1024 image (FluxKontext/inplace.py:396-402).  The fp32 reference runs on the GPU
-    through PyTorch (test infrastructure; ~0.3 s).  Also: the decode must beat the eager bf16 module of the same box by a wide margin
+    on the host cores (test infrastructure).  Also: the decode must beat the eager bf16 module of the same box by a wide margin
     (VERDICT round 5 next #4: <= 20 ms; eager was 75.8 ms)."""
     import time
     m, dec = _decoder_pair(5)
     z = torch.randn(1, 16, 128, 128, generator=torch.Generator().manual_seed(1))
+    ref = _fp32_on_cpu(lambda: m.decode(z.bfloat16().float(), return_dict=False)[0])     # 12 s on 64 host threads (MIOpen's fp32 path: 85 s)
     mg = m.cuda()
-    with torch.no_grad():
-        ref = mg.decode(z.bfloat16().float().cuda(), return_dict=False)[0].cpu()
     img = dec.decode(z.cuda())
     torch.cuda.synchronize()
     p = _psnr(img, ref)
