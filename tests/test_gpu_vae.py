@@ -211,13 +211,12 @@ def test_conv_stride2_vs_torch(H, W, cin, cout, geometry):
 @pytest.mark.parametrize("H,W", [(64, 64), (128, 192), (1024, 1024)])
 def test_encoder_vs_fp32_module(H, W):
     """VAE encode of the condition image (the host's prepare_latents; FluxKontext/inplace.py:210-226): moments (mean | logvar) of the HIP
-    encoder against the fp32 module, >= 40 dB; at 1024 x 1024 also the time next to the eager bf16 module."""
+    encoder against the fp32 module, >= 40 dB; at 1024 x 1024 also the time."""
     import time
     m = host_vae.seeded(7)
     enc = V.HipVaeEncoder(m.state_dict(), "cuda")
     x = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(H)).clamp(-1, 1)
     ref = _fp32_on_cpu(lambda: m.encoder(x.bfloat16().float()))
-    mg = m.cuda()
     got = enc.encode(x.cuda())
     torch.cuda.synchronize()
     assert got.shape == (1, 32, H // 8, W // 8) and torch.isfinite(got.float()).all()
@@ -235,18 +234,8 @@ def test_encoder_vs_fp32_module(H, W):
             enc.encode(xc)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 5 * 1e3
-        mb = mg.to(torch.bfloat16)
-        with torch.no_grad():
-            for _ in range(2):
-                mb.encoder(xc.bfloat16())
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                mb.encoder(xc.bfloat16())
-            torch.cuda.synchronize()
-        eager = (time.perf_counter() - t0) / 3 * 1e3
-        msg += f"; {ms:.1f} ms ({enc.flops(H, W) / ms / 1e9:.0f} TFLOP/s) vs eager bf16 {eager:.1f} ms"
-        assert ms < 0.5 * eager, (ms, eager)
+        msg += f"; {ms:.1f} ms ({enc.flops(H, W) / ms / 1e9:.0f} TFLOP/s; eager bf16 module: 37-38 ms, tools/f4_host_side.py)"
+        assert ms <= 15.0, ms
     print(msg)
     assert p >= 40.0, p
 
@@ -278,14 +267,13 @@ def test_decoder_small_latents_vs_fp32_module(h, w, groups, fuse):
 
 
 def test_decoder_1024_vs_fp32_module_and_timing():
-    """The headline size: 128 x 128 x 16 latent -> 1024 x 1024 image (FluxKontext/inplace.py:396-402).  The fp32 reference runs on the GPU
-    on the host cores (test infrastructure).  Also: the decode must beat the eager bf16 module of the same box by a wide margin
-    (VERDICT round 5 next #4: <= 20 ms; eager was 75.8 ms)."""
+    """The headline size: 128 x 128 x 16 latent -> 1024 x 1024 image (FluxKontext/inplace.py:396-402) against the fp32 module (run on the host
+    cores: test infrastructure).  Time: VERDICT round 5 next #4 asked for <= 20 ms (the eager bf16 module of the same box takes 73-74 ms:
+    tools/vae_decode_bench.py, profiles/r06_vae_decode_bench.json); asserted with slack for a slow box."""
     import time
     m, dec = _decoder_pair(5)
     z = torch.randn(1, 16, 128, 128, generator=torch.Generator().manual_seed(1))
     ref = _fp32_on_cpu(lambda: m.decode(z.bfloat16().float(), return_dict=False)[0])     # 12 s on 64 host threads (MIOpen's fp32 path: 85 s)
-    mg = m.cuda()
     img = dec.decode(z.cuda())
     torch.cuda.synchronize()
     p = _psnr(img, ref)
@@ -298,19 +286,9 @@ def test_decoder_1024_vs_fp32_module_and_timing():
         dec.decode(zc)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
-    mb = mg.to(torch.bfloat16)
-    with torch.no_grad():
-        for _ in range(2):
-            mb.decode(zc.bfloat16(), return_dict=False)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            mb.decode(zc.bfloat16(), return_dict=False)
-        torch.cuda.synchronize()
-    eager_ms = (time.perf_counter() - t0) / 3 * 1e3
-    print(f"[vae] 1024 x 1024: HIP decode vs fp32 module {p:.1f} dB; {ms:.1f} ms ({dec.flops(128, 128) / ms / 1e9:.0f} TFLOP/s) vs eager bf16 {eager_ms:.1f} ms")
+    print(f"[vae] 1024 x 1024: HIP decode vs fp32 module {p:.1f} dB; {ms:.1f} ms ({dec.flops(128, 128) / ms / 1e9:.0f} TFLOP/s)")
     assert p >= 40.0, p
-    assert ms < 0.5 * eager_ms, (ms, eager_ms)
+    assert ms <= 22.0, ms
 
 
 def test_decoder_rejects_what_it_does_not_implement():
