@@ -639,6 +639,12 @@ def attach(pipe, device="cuda"):
     if eng is None:
         eng = adopt_engine(pipe, device)
         pipe._regione_engine = eng
+        # the VAE too, HERE rather than inside the first edit (weights are re-laid once: ~0.5 s that would otherwise sit in that edit's
+        # decode_s / encode_s); a VAE of another layout returns None and keeps running on the host module
+        if getattr(pipe, "vae", None) is not None:
+            dev = eng.transformer.device
+            hip_vae_for(pipe, dev)
+            hip_vae_encoder_for(pipe, dev)
     return eng
 
 

@@ -176,7 +176,7 @@ def test_qwen_plus_list_of_condition_images():
 
 def test_flux_hosted_decode_runs_on_the_hip_vae():
     """a host whose `vae` is an AutoencoderKL (diffusers layout) gets its decoder adopted onto the HIP kernels
-    at the first hosted call (`pipe._regione_hip_vae`); the image equals the host module's own decode of the same latents (fp32 on the
+    at `enable()` (`pipe._regione_hip_vae`); the image equals the host module's own decode of the same latents (fp32 on the
     CPU) to >= 40 dB; `pipe._regione_hip_vae = False` keeps the host module; a stand-in VAE without that layout is left alone."""
     import math
     import host_vae
